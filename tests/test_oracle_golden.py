@@ -1,0 +1,139 @@
+"""Pins the CPU oracle (oracle/ts_oracle.c) before anything trusts it.
+
+Fixtures under tests/golden/ref_data are the reference's own data files
+(data/test.bed, data/oracle_theta.txt, data/oracle_beta.txt,
+data/output_theta.txt); .bim/.fam are regenerated line-count-only files
+(the reader only counts lines, src/snp.cc:104-139).
+"""
+import ctypes as C
+import hashlib
+import itertools
+import os
+
+import numpy as np
+import pytest
+import scipy.special as sp
+
+import oracle_py as op
+from conftest import REF_DATA
+
+
+def test_mt19937_known_answers(oracle_lib):
+    # GSL rng/test.c: rng_test(gsl_rng_mt19937, 4357, 1000, 1186927261);
+    # Matsumoto & Nishimura reference: seed 5489 -> 10000th output 4123659995
+    for seed, n, want in ((4357, 1000, 1186927261), (5489, 10000, 4123659995)):
+        r = op.gsl_mt19937(seed)
+        v = 0
+        for _ in range(n):
+            v = oracle_lib.orc_rng_get(C.byref(r))
+        assert v == want
+    # gsl_rng_set(r, 0) uses 4357
+    r0, r1 = op.gsl_mt19937(0), op.gsl_mt19937(4357)
+    assert [oracle_lib.orc_rng_get(C.byref(r0)) for _ in range(5)] == \
+           [oracle_lib.orc_rng_get(C.byref(r1)) for _ in range(5)]
+
+
+def test_uniform_int_range_and_scale(oracle_lib):
+    r = op.gsl_mt19937(7)
+    r2 = op.gsl_mt19937(7)
+    for n in (1, 2, 3, 200, 10000, 1000003):
+        scale = 0xFFFFFFFF // n
+        for _ in range(200):
+            got = oracle_lib.orc_rng_uniform_int(C.byref(r), n)
+            while True:  # gsl_rng_uniform_int: k = get()/scale until k < n
+                k = oracle_lib.orc_rng_get(C.byref(r2)) // scale
+                if k < n:
+                    break
+            assert got == k and 0 <= got < n
+
+
+def test_digamma_against_scipy(oracle_lib):
+    xs = np.concatenate([np.logspace(-8, 8, 4000), np.linspace(0.01, 40, 4000)])
+    got = np.array([oracle_lib.orc_digamma(float(x)) for x in xs])
+    ref = sp.digamma(xs)
+    assert np.max(np.abs(got - ref) / (1 + np.abs(ref))) < 2e-15
+
+
+def test_gamma_sampler_moments(oracle_lib):
+    r = op.gsl_mt19937(99)
+    x = np.array([oracle_lib.orc_ran_gamma(C.byref(r), 100.0, 0.01) for _ in range(20000)])
+    assert abs(x.mean() - 1.0) < 5e-3          # mean a*b = 1
+    assert abs(x.var() - 0.01) < 1e-3          # var a*b^2 = 0.01
+    y = np.array([oracle_lib.orc_ran_gamma(C.byref(r), 0.5, 2.0) for _ in range(20000)])
+    assert abs(y.mean() - 1.0) < 5e-2
+
+
+def test_bed_decode_rule(oracle_lib):
+    # src/snp.cc:203-216: 00->0, 01->missing(3), 10->1, 11->2, LSB first
+    n = 7
+    o = op.Oracle(n, 2, 2)
+    codes = [0b00, 0b01, 0b10, 0b11, 0b11, 0b10, 0b00]
+    want = [0, 3, 1, 2, 2, 1, 0]
+    col = np.zeros((2, 2), dtype=np.uint8)
+    for i, c in enumerate(codes):
+        col[0, i // 4] |= c << (2 * (i % 4))
+    col[1] = 0xFF
+    missing = o.load_bed_payload(col)
+    assert [oracle_lib.orc_y(o.s, i, 0) for i in range(n)] == want
+    assert [oracle_lib.orc_y(o.s, i, 1) for i in range(n)] == [2] * n
+    assert missing == 1
+    assert not oracle_lib.orc_kv_ok(o.s, 1, 0) and oracle_lib.orc_kv_ok(o.s, 0, 0)
+    o.set_heldout(0, [2])
+    assert not oracle_lib.orc_kv_ok(o.s, 2, 0)
+    assert list(o.heldout_locs()) == [0] and list(o.heldout_indivs(0)) == [2]
+
+
+@pytest.fixture(scope="module")
+def config1_run():
+    """data/run.sh:1 -- N=200 L=10000 K=3 -seed 1234 -rfreq 1000 -nthreads 1."""
+    o = op.Oracle(200, 10000, 3)
+    o.read_bed_file(os.path.join(REF_DATA, "test.bed"))
+    res = o.run(seed=1234, reportfreq=1000)
+    return o, res
+
+
+def _best_perm_rmse(a, b):
+    k = a.shape[1]
+    return min(np.sqrt(np.mean((a[:, list(p)] - b) ** 2)) for p in itertools.permutations(range(k)))
+
+
+def _fmt(a):  # save_gamma format, src/snpsamplinge.cc:563-572
+    return "".join("".join("%.8f\t" % v for v in row) + "\n" for row in a)
+
+
+def test_config1_matches_reference_probe(config1_run):
+    """Numbers the survey recorded from the REAL reference sources on this input
+    (reference built there with the same
+    mt19937 / Marsaglia-Tsang / digamma restatements): validation.txt lines,
+    self-termination at iter 16050 and the md5 of theta.txt."""
+    o, res = config1_run
+    assert res["stopped"] and res["final_iter"] == 16050
+    lines = res["lines"]
+    assert len(lines) == 17
+    assert lines[0][0] == 0 and lines[0][2] == 1000 and "%.9f" % lines[0][1] == "-1.169339294"
+    assert lines[1][0] == 1050 and "%.9f" % lines[1][1] == "-0.732008912"
+    assert abs(lines[-1][1] - (-0.7314)) < 1e-3
+    md5 = hashlib.md5(_fmt(o.theta()).encode()).hexdigest()
+    assert md5 == "da9e6e57d6fed4446ead30c8d841e010"
+
+
+def test_config1_against_reference_fixtures(config1_run):
+    """Statistical pin against the reference's data/oracle_*.txt ground truth and
+    the shipped data/output_theta.txt sample output."""
+    o, _ = config1_run
+    theta = o.theta()
+    truth = np.loadtxt(os.path.join(REF_DATA, "oracle_theta.txt"))
+    shipped = np.loadtxt(os.path.join(REF_DATA, "output_theta.txt"))
+    assert theta.shape == truth.shape == shipped.shape == (200, 3)
+    assert _best_perm_rmse(theta, truth) <= 0.06
+    assert _best_perm_rmse(theta, shipped) <= 0.04       # same fit as the authors' run
+    assert _best_perm_rmse(shipped, truth) <= 0.06       # sanity of the fixture itself
+    # gamma row sums converge to K*alpha + 2L (each step maps S -> (1-rho)S + rho(K alpha + 2L))
+    assert np.allclose(o.gamma().sum(1), 3 * (1 / 3) + 2 * 10000, rtol=1e-6)
+    # beta: allele coding is flipped w.r.t. oracle_beta.txt (beta.txt == 1 - oracle_beta)
+    perm = min(itertools.permutations(range(3)),
+               key=lambda p: np.mean((theta[:, list(p)] - truth) ** 2))
+    o.compute_all_lambda()  # data/run.sh:3 (-compute-beta sweep, same hot path)
+    beta = o.ebeta()[:, list(perm)]
+    tb = np.loadtxt(os.path.join(REF_DATA, "oracle_beta.txt"))
+    assert np.sqrt(np.mean(((1 - beta) - tb) ** 2)) <= 0.05
