@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""SNP-minibatch updates/sec of the MI355X SVI engine (BASELINE.json metric).
+
+One "step" = one SNP-minibatch update = tsamd_snp_update semantics
+(optimize_lambda(loc), src/snpsamplinge.cc:320-366, plus the gamma/Elogtheta
+step of that SNP, :695-740), on synthetic PSD genotypes resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+one rank per GPU; individuals are sharded across ranks and the per-pass
+lambda statistics are all-reduced by RCCL inside libtsamd (strong scaling:
+N individuals fixed).  torch.distributed (gloo) only carries the RCCL unique
+id and the timing barriers.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--n", type=int, default=1_000_000, help="individuals (global)")
+    ap.add_argument("--l", type=int, default=1_000_000, help="SNP locations (capped to what fits in HBM)")
+    ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=20240607)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event pass-kernel timing leg")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import terastructure_amd as ts
+
+    n, k = args.n, args.k
+    sb, sc = ts.shard_range(n, rank, world)
+    colstride = ((sc + 511) // 512 * 512) // 4
+
+    # how many SNP columns fit next to the per-individual and per-location state
+    probe = ts.Engine(min(n, 4096), 16, k, device=local_rank)
+    free_b, total_b = probe.mem_info()
+    probe.close()
+    per_loc = colstride + 2 * (2 * k * 8)          # column + lambda + exp(Elogbeta)
+    reserve = 4 * (sc * k * 8) + (6 << 30)          # w, gamma, synth scratch + headroom
+    l = int(min(args.l, max(64, (free_b - reserve) // per_loc)))
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([l], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        l = int(t.item())
+
+    t_setup = time.time()
+    eng = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
+    if world > 1:
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0])
+
+    # synthetic PSD data: theta ~ Dir(0.2), beta ~ U(0.05, 0.95), y ~ Bin(2, theta.beta)
+    rng = np.random.default_rng(args.seed)
+    theta = rng.dirichlet(np.full(k, 0.2), size=n)[sb:sb + sc]
+    chunk = 1 << 17
+    brng = np.random.default_rng(args.seed + 1)
+    for l0 in range(0, l, chunk):
+        beta = brng.uniform(0.05, 0.95, size=(min(chunk, l - l0), k))
+        eng.synth_genotypes(theta, beta, first_loc=l0, seed=args.seed)
+    eng.set_gamma(np.random.default_rng(args.seed + 2).gamma(100.0, 0.01, size=(n, k))[sb:sb + sc])
+    del theta
+    setup_s = time.time() - t_setup
+
+    locs = np.random.default_rng(args.seed + 3).integers(0, l, size=args.warmup + args.steps).astype(np.uint32)
+
+    def barrier():
+        eng.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    if args.warmup:
+        eng.run_schedule(locs[:args.warmup])
+    barrier()
+    p0 = eng.total_passes()
+    t0 = time.perf_counter()
+    eng.run_schedule(locs[args.warmup:])
+    eng.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    passes = eng.total_passes() - p0
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    value = args.steps / dt
+    mean_passes = passes / max(1, args.steps)
+
+    # ---- roofline of the dominant kernel (plain pass, ts_pass<KT,false>) ------------
+    # algorithmic bytes per launch = 8*N_shard*K (weights) + N_shard/4 (2-bit column)
+    roofline = None
+    if not args.no_profile:
+        prof_steps = min(args.steps, 300)
+        eng.profile_enable(True)
+        eng.run_schedule(locs[args.warmup:args.warmup + prof_steps])
+        eng.synchronize()
+        pr = eng.profile_read()
+        eng.profile_enable(False)
+        if pr["pass_launches"]:
+            avg_s = pr["pass_ms"] / pr["pass_launches"] * 1e-3
+            alg_bytes = 8.0 * sc * k + sc / 4.0
+            achieved = alg_bytes / avg_s / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pass_kernel_pmc.json")
+            if os.path.exists(pmc):
+                try:
+                    rec = json.load(open(pmc))
+                    if rec.get("n") == n and rec.get("k") == k and rec.get("n_gpus") == world:
+                        traffic = rec.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {
+                "bound": "hbm", "kernel": "ts_pass<KT,false>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_us": round(avg_s * 1e6, 3), "launches_timed": pr["pass_launches"],
+                "first_pass_avg_us": round(pr["first_ms"] / max(1, pr["first_launches"]) * 1e3, 3),
+            }
+
+    # ---- CPU baseline: the oracle ("port") on the host cores, bounded sample ---------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        import oracle_py as op
+
+        cores = args.cpu_threads or (os.cpu_count() or 1)
+        ls = 8  # sample columns; per-update cost does not depend on L
+        orc = op.Oracle(n, ls, k, nthreads=cores, gamma_scale=float(l))
+        sample = np.stack([eng.download_bed(int(j)) for j in range(ls)])
+        orc.load_bed_payload(sample)
+        orc.set_gamma(np.random.default_rng(args.seed + 2).gamma(100.0, 0.01, size=(n, k)))
+        done, tc0 = 0, time.perf_counter()
+        orc.snp_update(0)  # untimed: first call has no gamma step to apply
+        tc0 = time.perf_counter()
+        while True:
+            orc.snp_update((done + 1) % ls)
+            done += 1
+            if time.perf_counter() - tc0 > args.cpu_seconds or done >= args.steps:
+                break
+        cdt = time.perf_counter() - tc0
+        cpu = {"value": round(done / cdt, 4), "unit": "SNP-minibatch updates/s", "cores": cores,
+               "kind": "port",
+               "sample": f"{done} updates (10 passes + gamma step each) at N={n}, K={k} on {ls} of the "
+                         f"benchmark's own columns, oracle/ts_oracle.c with {cores} OpenMP threads "
+                         f"in the reference's work partition"}
+        orc.close()
+
+    if rank == 0:
+        alg_update = (mean_passes + 4) * 8.0 * n * k + (mean_passes + 1) * n / 4.0 + 8.0 * n
+        out = {
+            "metric": "SNP-minibatch updates/sec (N x K phi+accum) at N=1M K=8",
+            "value": round(value, 2), "unit": "updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic PSD N={n} individuals x L={l} SNPs, K={k}, 2-bit genotypes "
+                                   f"HBM-resident, individuals sharded over {world} GPU(s)",
+                       "n": n, "l": l, "k": k, "l_requested": args.l,
+                       "parallelism": f"individual-shard x{world}"},
+            "mean_inner_passes": round(mean_passes, 3),
+            "nk_pass_per_s": round(value * mean_passes * n * k, 1),
+            "update_algorithmic_bytes": alg_update,
+            "update_hbm_frac_of_peak": round(alg_update * value / (world * HBM_PEAK_GBS * 1e9), 4),
+            "setup_s": round(setup_s, 1),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

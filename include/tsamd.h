@@ -1,0 +1,160 @@
+/*
+ * tsamd.h -- C ABI of the MI355X-native SNP-minibatch SVI engine
+ * (libtsamd.so, built from terastructure_amd/csrc/ with hipcc for gfx950).
+ *
+ * The reference has no plugin/FFI layer: its C++ host calls
+ * SNPSamplingE::optimize_lambda(loc) directly from the main thread
+ * (callers: src/snpsamplinge.cc:425 infer, :374 compute_all_lambda,
+ * :405 compute_and_save_beta, src/snpsamplinge.hh:332 snp_likelihood).
+ * This header is that seam as a C ABI: plain pointers and sizes, fp64
+ * row-major arrays in the reference's shapes, no torch/HIP types.
+ *
+ * Conventions
+ *  - every call returns 0 on success or a negative TSAMD_E* code and never
+ *    calls exit()/assert() (the reference does, e.g. src/snpsamplinge.cc:69-72);
+ *    tsamd_last_error() gives the message.
+ *  - one caller thread per context; calls are synchronous unless stated.
+ *  - a context owns one shard of individuals [shard_begin, shard_begin +
+ *    shard_count) given by tsamd_shard_range(n, rank, world); per-individual
+ *    arrays passed in/out cover THAT shard only (world == 1: everyone).
+ *  - locations are 0-based SNP indices < l.
+ */
+#ifndef TSAMD_H
+#define TSAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSAMD_ABI_VERSION 1
+
+#define TSAMD_OK 0
+#define TSAMD_EINVAL (-1)       /* bad argument */
+#define TSAMD_EHIP (-2)         /* HIP runtime error */
+#define TSAMD_ENOMEM (-3)       /* host or device allocation failed */
+#define TSAMD_ECOMM (-4)        /* RCCL error / communicator missing */
+#define TSAMD_EUNSUPPORTED (-5) /* e.g. K above the compiled maximum */
+
+#define TSAMD_MAX_K 32
+#define TSAMD_COMM_ID_BYTES 128
+
+typedef struct tsamd_ctx tsamd_ctx;
+
+/* Model constants; defaults are the reference's compile-time values. */
+typedef struct tsamd_config {
+  uint32_t struct_size; /* sizeof(tsamd_config), ABI check */
+  uint32_t n;           /* individuals, global            (-n, src/main.cc:115) */
+  uint32_t l;           /* SNP locations                  (-l, src/main.cc:121) */
+  uint32_t k;           /* populations                    (-k, src/main.cc:118) */
+  double alpha;         /* 1/k                            src/env.hh:209 */
+  double eta0, eta1;    /* 1, 1                           src/env.hh:221-222 */
+  double nodetau0;      /* 2 (env 1, +1 in the engine)    src/snpsamplinge.cc:16 */
+  double nodekappa;     /* 0.5                            src/env.hh:230 */
+  uint32_t max_inner;   /* online_iterations: 10; 100 in -compute-beta  src/env.hh:232, src/snpsamplinge.cc:75 */
+  double conv_thresh;   /* meanchangethresh 1e-3          src/env.hh:208 */
+  double gamma_scale;   /* = l                            src/snpsamplinge.cc:702 */
+  int32_t device;       /* HIP device ordinal */
+  uint32_t rank, world; /* individual sharding; world == 1 for a single GPU */
+  uint32_t flags;       /* TSAMD_FLAG_* */
+} tsamd_config;
+
+#define TSAMD_FLAG_SPLIT_EPILOGUE 1u /* run the K x 2 epilogue as its own kernel even on one GPU */
+#define TSAMD_FLAG_NO_GRAPH 2u       /* tsamd_run_schedule launches eagerly instead of replaying a hipGraph */
+
+int tsamd_abi_version(void);
+void tsamd_default_config(tsamd_config *cfg, uint32_t n, uint32_t l, uint32_t k);
+/* contiguous shards of ceil(n/world) rounded up to a multiple of 4 individuals
+ * (byte-aligned slices of a .bed column); mirrors split_all_indivs
+ * (src/snpsamplinge.cc:298-318) with GPUs in place of threads. */
+void tsamd_shard_range(uint32_t n, uint32_t rank, uint32_t world, uint32_t *begin, uint32_t *count);
+
+/* replaces SNPSamplingE::SNPSamplingE state allocation + init_lambda
+ * (src/snpsamplinge.cc:6-37, :239-250): lambda = eta, gamma = 1, c_n = 0,
+ * all genotypes missing until uploaded. */
+int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out);
+void tsamd_destroy(tsamd_ctx *ctx);
+/* message of the last failing call on ctx (ctx == NULL: last tsamd_create failure) */
+const char *tsamd_last_error(const tsamd_ctx *ctx);
+
+/* replaces SNP::read_bed's decode loop (src/snp.cc:195-228): raw PLINK
+ * SNP-major payload after the 3 magic bytes, n_locs columns of bytes_per_snp =
+ * ceil(n/4) bytes (GLOBAL n); the context copies its shard's byte range and
+ * keeps the 2-bit codes packed in HBM.  The host buffer is not retained. */
+int tsamd_upload_bed(tsamd_ctx *ctx, const uint8_t *payload, uint64_t bytes_per_snp,
+                     uint32_t first_loc, uint32_t n_locs);
+/* shard's column as ceil(shard_count/4) PLINK bytes, held-out entries shown as missing */
+int tsamd_download_bed(tsamd_ctx *ctx, uint32_t loc, uint8_t *out, uint64_t out_bytes);
+
+/* replaces _validation_map inserts (src/snpsamplinge.cc:213-217) and their
+ * kv_ok effect (src/snpsamplinge.hh:389-408): (indiv, loc) then behaves as
+ * missing in every pass and gamma step.  indivs are GLOBAL ids; ids outside
+ * the shard are ignored.  True genotypes are kept for tsamd_heldout_loglik. */
+int tsamd_set_heldout(tsamd_ctx *ctx, uint32_t loc, const uint32_t *indivs, uint32_t count);
+
+/* gamma [shard_count][k] row-major.  set also refreshes Elogtheta
+ * (estimate_all_theta, src/snpsamplinge.cc:595-609); c_n is left alone. */
+int tsamd_set_gamma(tsamd_ctx *ctx, const double *gamma);
+int tsamd_get_gamma(tsamd_ctx *ctx, double *gamma);
+int tsamd_get_theta(tsamd_ctx *ctx, double *theta);         /* gamma / sum_k gamma */
+int tsamd_get_elogtheta(tsamd_ctx *ctx, double *elogtheta); /* psi(gamma) - psi(sum) */
+int tsamd_set_counts(tsamd_ctx *ctx, const uint32_t *c);    /* _c_indiv, src/snpsamplinge.cc:18 */
+int tsamd_get_counts(tsamd_ctx *ctx, uint32_t *c);
+
+/* lambda[loc] is [k][2]; persists across visits to a location.  set also
+ * refreshes Elogbeta (estimate_beta, src/snpsamplinge.cc:279-296). */
+int tsamd_set_lambda(tsamd_ctx *ctx, uint32_t loc, const double *lambda);
+int tsamd_get_lambda(tsamd_ctx *ctx, uint32_t first_loc, uint32_t n_locs, double *lambda /* [n_locs][k][2] */);
+int tsamd_get_ebeta(tsamd_ctx *ctx, uint32_t first_loc, uint32_t n_locs, double *ebeta /* [n_locs][k] */);
+int tsamd_get_elogbeta(tsamd_ctx *ctx, uint32_t first_loc, uint32_t n_locs, double *elogbeta /* [n_locs][k][2] */);
+
+/* replaces one SNPSamplingE::optimize_lambda(loc) call (src/snpsamplinge.cc:320-366)
+ * with the -nthreads 1 worker semantics (PhiRunnerE::do_work, :649-686): first the
+ * pending gamma/Elogtheta step of the previous call is applied iff that call had
+ * hol_mode == 0, using the phi of its LAST pass; then up to max_inner passes for loc;
+ * then this call becomes the pending one.  inner_iters (may be NULL) = passes run. */
+int tsamd_snp_update(tsamd_ctx *ctx, uint32_t loc, int hol_mode, uint32_t *inner_iters);
+/* the same n times with no host round trip (results identical to n x tsamd_snp_update);
+ * asynchronous: returns after enqueueing, tsamd_synchronize() waits. */
+int tsamd_run_schedule(tsamd_ctx *ctx, const uint32_t *locs, uint32_t n, int hol_mode);
+int tsamd_synchronize(tsamd_ctx *ctx);
+/* total inner passes executed by tsamd_run_schedule / snp_update calls since creation */
+int tsamd_total_passes(tsamd_ctx *ctx, uint64_t *passes);
+/* drop the pending gamma step (a new process starts with none: `first`, :652) */
+int tsamd_clear_pending(tsamd_ctx *ctx);
+
+/* replaces the second half of snp_likelihood (src/snpsamplinge.hh:336-360) for the
+ * held-out individuals of loc in this shard: sum of log(max(C(2,y) q^y (1-q)^(2-y), 1e-30)),
+ * q = sum_k Ebeta[loc][k] * Etheta[n][k]; ascending individual order. */
+int tsamd_heldout_loglik(tsamd_ctx *ctx, uint32_t loc, double *sum, uint32_t *count);
+
+/* ---- multi-GPU: individuals sharded, lambda_t all-reduced per pass over RCCL ----
+ * rank 0 calls tsamd_comm_unique_id and ships the bytes to every rank (any
+ * side channel, e.g. torch.distributed broadcast); every rank then calls
+ * tsamd_comm_init with its context (cfg.rank / cfg.world).  Replaces the
+ * main-thread reduction over workers (src/snpsamplinge.cc:337-352). */
+int tsamd_comm_unique_id(uint8_t id[TSAMD_COMM_ID_BYTES]);
+int tsamd_comm_init(tsamd_ctx *ctx, const uint8_t id[TSAMD_COMM_ID_BYTES]);
+
+/* ---- measurement / synthetic workloads ---------------------------------------- */
+/* Pritchard-Stephens-Donnelly genotypes straight into HBM for columns
+ * [first_loc, first_loc + n_locs): y ~ Binomial(2, sum_k theta[n][k] * beta[j][k]),
+ * theta [shard_count][k], beta [n_locs][k], counter-based RNG keyed by
+ * (seed, global individual, location) so any sharding gives the same matrix.
+ * missing_rate in [0,1) marks entries missing. */
+int tsamd_synth_genotypes(tsamd_ctx *ctx, const double *theta, const double *beta,
+                          uint32_t first_loc, uint32_t n_locs, uint64_t seed, double missing_rate);
+/* HIP-event timing of the plain pass kernel launches issued by tsamd_run_schedule:
+ * enable, run, then read the launch count and the summed duration. */
+int tsamd_profile_enable(tsamd_ctx *ctx, int on);
+int tsamd_profile_read(tsamd_ctx *ctx, uint64_t *pass_launches, double *pass_ms_total,
+                       uint64_t *first_launches, double *first_ms_total);
+/* device memory in bytes currently free / total on the context's device */
+int tsamd_mem_info(tsamd_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

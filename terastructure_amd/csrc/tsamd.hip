@@ -1,0 +1,894 @@
+// libtsamd.so -- C ABI (include/tsamd.h) over the HIP kernels in tsamd_kernels.h.
+// gfx950 only.  No CPU fallback anywhere: every entry point drives the device.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "tsamd.h"
+#include "tsamd_kernels.h"
+
+using namespace tsamd;
+
+namespace {
+
+std::string g_create_error;
+
+struct RcclApi {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+  bool load() {
+    if (handle) return true;
+    // RTLD_NOLOAD first: inside a torch process reuse the RCCL torch already mapped.
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *nm : names) {
+      handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+      if (handle) break;
+    }
+    for (const char *nm : names) {
+      if (handle) break;
+      handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!handle) {
+      error = std::string("dlopen librccl failed: ") + dlerror();
+      return false;
+    }
+    GetUniqueId = (decltype(GetUniqueId))dlsym(handle, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(handle, "ncclCommInitRank");
+    AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce");
+    CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+    GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString) {
+      error = "librccl is missing a required symbol";
+      return false;
+    }
+    return true;
+  }
+};
+RcclApi g_rccl;
+
+struct HeldLoc {
+  std::vector<uint32_t> local_ids;  // ascending
+  std::vector<uint8_t> ytrue;       // 0/1/2
+};
+
+constexpr uint32_t kProfCap = 8192;
+constexpr uint32_t kGraphSnps = 16;  // SNPs per captured graph
+
+__global__ void ts_begin_schedule(Ctl *ctl, uint32_t n) {
+  ctl->cursor = 0u;
+  ctl->sched_len = n;
+}
+
+}  // namespace
+
+struct tsamd_ctx {
+  tsamd_config cfg{};
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  uint32_t n_begin = 0, n_local = 0, npad = 0;
+  int kt = 0;
+  uint32_t grid = 0;
+  DevParams p{};
+  uint32_t *d_sched = nullptr;
+  uint32_t sched_cap = 0;
+  uint8_t *h_stage = nullptr;  // pinned staging for uploads
+  size_t stage_bytes = 0;
+  std::map<uint32_t, HeldLoc> held;
+  ncclComm_t comm = nullptr;
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev_pass, ev_first;  // start/stop pairs
+  uint32_t n_ev_pass = 0, n_ev_first = 0;
+  uint64_t prof_pass_n = 0, prof_first_n = 0;
+  double prof_pass_ms = 0, prof_first_ms = 0;
+  // hipGraph replay of the per-SNP kernel sequence
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  uint32_t graph_snps = 0;
+  std::vector<std::vector<uint32_t>> keepalive;  // host schedules of copies possibly still in flight
+  std::string err;
+};
+
+namespace {
+
+int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                     \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? TSAMD_ENOMEM : TSAMD_EHIP, "%s: %s", #expr, \
+                  hipGetErrorString(e_));                                                      \
+  } while (0)
+
+#define CHECK_CTX(ctx) \
+  if (!(ctx)) return TSAMD_EINVAL
+
+int pick_kt(uint32_t k) {
+  static const int kts[] = {2, 3, 4, 6, 8, 12, 16, 20, 24, 32};
+  for (int v : kts)
+    if ((int)k <= v) return v;
+  return 0;
+}
+
+template <typename F>
+auto dispatch_kt(int kt, F &&f) {
+  switch (kt) {
+    case 2: return f(std::integral_constant<int, 2>{});
+    case 3: return f(std::integral_constant<int, 3>{});
+    case 4: return f(std::integral_constant<int, 4>{});
+    case 6: return f(std::integral_constant<int, 6>{});
+    case 8: return f(std::integral_constant<int, 8>{});
+    case 12: return f(std::integral_constant<int, 12>{});
+    case 16: return f(std::integral_constant<int, 16>{});
+    case 20: return f(std::integral_constant<int, 20>{});
+    case 24: return f(std::integral_constant<int, 24>{});
+    default: return f(std::integral_constant<int, 32>{});
+  }
+}
+
+__global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = (i & 1) ? v1 : v0;
+}
+
+void launch_pass(tsamd_ctx *c, bool first) {
+  dispatch_kt(c->kt, [&](auto KTc) {
+    constexpr int KT = decltype(KTc)::value;
+    if (first)
+      hipLaunchKernelGGL((ts_pass<KT, true>), dim3(c->grid), dim3(kBlock), 0, c->stream, c->p);
+    else
+      hipLaunchKernelGGL((ts_pass<KT, false>), dim3(c->grid), dim3(kBlock), 0, c->stream, c->p);
+    return 0;
+  });
+}
+
+void launch_epilogue(tsamd_ctx *c, bool first) {
+  if (first)
+    hipLaunchKernelGGL((ts_epilogue<true>), dim3(1), dim3(64), 0, c->stream, c->p);
+  else
+    hipLaunchKernelGGL((ts_epilogue<false>), dim3(1), dim3(64), 0, c->stream, c->p);
+}
+
+bool split_epilogue(const tsamd_ctx *c) { return c->p.multi != 0; }
+
+// one pass = pass kernel [+ all-reduce] [+ epilogue kernel]
+int enqueue_pass(tsamd_ctx *c, bool first) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->prof) {
+    auto &evs = first ? c->ev_first : c->ev_pass;
+    uint32_t &n = first ? c->n_ev_first : c->n_ev_pass;
+    if (n < kProfCap) {
+      if (evs.size() < 2 * (size_t)(n + 1)) {
+        hipEvent_t a, b;
+        HIP_TRY(c, hipEventCreate(&a));
+        HIP_TRY(c, hipEventCreate(&b));
+        evs.push_back(a);
+        evs.push_back(b);
+      }
+      e0 = evs[2 * n];
+      e1 = evs[2 * n + 1];
+      n++;
+      HIP_TRY(c, hipEventRecord(e0, c->stream));
+    }
+  }
+  launch_pass(c, first);
+  if (e1) HIP_TRY(c, hipEventRecord(e1, c->stream));
+  if (split_epilogue(c)) {
+    if (c->comm) {
+      ncclResult_t r = g_rccl.AllReduce(c->p.ctl->lt, c->p.ctl->lt_sum, 2 * c->cfg.k, ncclDouble, ncclSum, c->comm,
+                                        c->stream);
+      if (r != ncclSuccess) return fail(c, TSAMD_ECOMM, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+    } else {
+      HIP_TRY(c, hipMemcpyAsync(c->p.ctl->lt_sum, c->p.ctl->lt, sizeof(double) * 2 * c->cfg.k,
+                                hipMemcpyDeviceToDevice, c->stream));
+    }
+    launch_epilogue(c, first);
+  }
+  return TSAMD_OK;
+}
+
+int enqueue_snp(tsamd_ctx *c) {
+  int rc = enqueue_pass(c, true);
+  for (uint32_t i = 1; rc == TSAMD_OK && i < c->cfg.max_inner; ++i) rc = enqueue_pass(c, false);
+  return rc;
+}
+
+void destroy_graph(tsamd_ctx *c) {
+  if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
+  if (c->graph) hipGraphDestroy(c->graph);
+  c->graph_exec = nullptr;
+  c->graph = nullptr;
+  c->graph_snps = 0;
+}
+
+// capture `snps` consecutive SNP sequences; kernels read everything that varies
+// (location, pending state) from device memory, so the graph is replayable as is.
+int build_graph(tsamd_ctx *c, uint32_t snps) {
+  destroy_graph(c);
+  HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int rc = TSAMD_OK;
+  for (uint32_t s = 0; s < snps && rc == TSAMD_OK; ++s) rc = enqueue_snp(c);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(c->stream, &g);
+  if (rc != TSAMD_OK) {
+    if (g) hipGraphDestroy(g);
+    return rc;
+  }
+  if (e != hipSuccess) return fail(c, TSAMD_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  c->graph = g;
+  HIP_TRY(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+  c->graph_snps = snps;
+  return TSAMD_OK;
+}
+
+int ensure_stage(tsamd_ctx *c, size_t bytes) {
+  if (c->stage_bytes >= bytes) return TSAMD_OK;
+  if (c->h_stage) hipHostFree(c->h_stage);
+  c->h_stage = nullptr;
+  c->stage_bytes = 0;
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_stage, bytes, hipHostMallocDefault));
+  c->stage_bytes = bytes;
+  return TSAMD_OK;
+}
+
+// row-major [n_local][K] host -> k-major [K][npad] device (padding rows = pad)
+int upload_kmajor(tsamd_ctx *c, const double *rows, double *dst, double pad) {
+  const size_t K = c->cfg.k, np = c->npad, nl = c->n_local;
+  std::vector<double> tmp(K * np, pad);
+  for (size_t n = 0; n < nl; ++n)
+    for (size_t k = 0; k < K; ++k) tmp[k * np + n] = rows[n * K + k];
+  HIP_TRY(c, hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TSAMD_OK;
+}
+
+int export_indiv(tsamd_ctx *c, int mode, double *out) {
+  const size_t K = c->cfg.k, nl = c->n_local;
+  double *d_out = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&d_out, nl * K * sizeof(double)));
+  hipLaunchKernelGGL(ts_export_indiv, dim3((nl + 255) / 256), dim3(256), 0, c->stream, c->p.gam, c->npad,
+                     (uint32_t)K, (uint32_t)nl, (const uint32_t *)nullptr, mode, d_out);
+  hipError_t e = hipMemcpyAsync(out, d_out, nl * K * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_out);
+  if (e != hipSuccess) return fail(c, TSAMD_EHIP, "export_indiv: %s", hipGetErrorString(e));
+  return TSAMD_OK;
+}
+
+int check_locs(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs) {
+  if ((uint64_t)first_loc + n_locs > c->cfg.l)
+    return fail(c, TSAMD_EINVAL, "location range [%u, %u) exceeds l = %u", first_loc, first_loc + n_locs, c->cfg.l);
+  return TSAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsamd_abi_version(void) { return TSAMD_ABI_VERSION; }
+
+void tsamd_default_config(tsamd_config *cfg, uint32_t n, uint32_t l, uint32_t k) {
+  memset(cfg, 0, sizeof *cfg);
+  cfg->struct_size = sizeof *cfg;
+  cfg->n = n;
+  cfg->l = l;
+  cfg->k = k;
+  cfg->alpha = k ? 1.0 / (double)k : 0.0;
+  cfg->eta0 = 1.0;
+  cfg->eta1 = 1.0;
+  cfg->nodetau0 = 2.0;
+  cfg->nodekappa = 0.5;
+  cfg->max_inner = 10;
+  cfg->conv_thresh = 1e-3;
+  cfg->gamma_scale = (double)l;
+  cfg->device = 0;
+  cfg->rank = 0;
+  cfg->world = 1;
+  cfg->flags = 0;
+}
+
+void tsamd_shard_range(uint32_t n, uint32_t rank, uint32_t world, uint32_t *begin, uint32_t *count) {
+  if (world == 0) world = 1;
+  uint64_t per = ((uint64_t)n + world - 1) / world;
+  per = (per + 3) / 4 * 4;
+  uint64_t b = std::min<uint64_t>((uint64_t)rank * per, n);
+  uint64_t e = std::min<uint64_t>(b + per, n);
+  if (begin) *begin = (uint32_t)b;
+  if (count) *count = (uint32_t)(e - b);
+}
+
+const char *tsamd_last_error(const tsamd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void tsamd_destroy(tsamd_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->dev);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  destroy_graph(c);
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  for (auto e : c->ev_pass) hipEventDestroy(e);
+  for (auto e : c->ev_first) hipEventDestroy(e);
+  hipFree(c->p.bed);
+  hipFree(c->p.w);
+  hipFree(c->p.gam);
+  hipFree(c->p.cnt);
+  hipFree(c->p.lam);
+  hipFree(c->p.eb);
+  hipFree(c->p.ctl);
+  hipFree(c->p.partials);
+  hipFree(c->d_sched);
+  if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
+  if (!cfg || !out) return fail(nullptr, TSAMD_EINVAL, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(tsamd_config))
+    return fail(nullptr, TSAMD_EINVAL, "tsamd_config size %u != %zu (ABI mismatch)", cfg->struct_size,
+                sizeof(tsamd_config));
+  if (cfg->n == 0 || cfg->l == 0 || cfg->k == 0) return fail(nullptr, TSAMD_EINVAL, "n, l, k must be positive");
+  if (cfg->l >= 0x80000000u) return fail(nullptr, TSAMD_EINVAL, "l must be < 2^31");
+  if (cfg->k > TSAMD_MAX_K)
+    return fail(nullptr, TSAMD_EUNSUPPORTED, "k = %u above compiled maximum %d", cfg->k, TSAMD_MAX_K);
+  if (cfg->max_inner == 0) return fail(nullptr, TSAMD_EINVAL, "max_inner must be >= 1");
+  if (cfg->world == 0 || cfg->rank >= cfg->world) return fail(nullptr, TSAMD_EINVAL, "bad rank/world");
+  uint32_t b = 0, cnt = 0;
+  tsamd_shard_range(cfg->n, cfg->rank, cfg->world, &b, &cnt);
+  if (cnt == 0) return fail(nullptr, TSAMD_EINVAL, "rank %u of %u owns no individuals (n = %u)", cfg->rank, cfg->world, cfg->n);
+
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, TSAMD_EHIP, "no HIP device available (%s): libtsamd has no CPU path",
+                hipGetErrorString(e));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, TSAMD_EINVAL, "device %d out of range", cfg->device);
+
+  tsamd_ctx *c = new tsamd_ctx();
+  c->cfg = *cfg;
+  c->dev = cfg->device;
+  c->n_begin = b;
+  c->n_local = cnt;
+  c->npad = (cnt + 511u) / 512u * 512u;
+  c->kt = pick_kt(cfg->k);
+#define CREATE_TRY(expr)                                                                          \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      int code_ = fail(nullptr, e_ == hipErrorOutOfMemory ? TSAMD_ENOMEM : TSAMD_EHIP, "%s: %s", \
+                       #expr, hipGetErrorString(e_));                                             \
+      tsamd_destroy(c);                                                                           \
+      return code_;                                                                               \
+    }                                                                                             \
+  } while (0)
+  CREATE_TRY(hipSetDevice(c->dev));
+  CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+  DevParams &p = c->p;
+  const size_t K = cfg->k, np = c->npad, L = cfg->l;
+  p.colstride = np / 4;  // npad multiple of 512 -> multiple of 128 bytes
+  p.npad = c->npad;
+  p.npairs = c->npad / 2;
+  p.K = cfg->k;
+  p.max_inner = cfg->max_inner;
+  p.multi = (cfg->world > 1 || (cfg->flags & TSAMD_FLAG_SPLIT_EPILOGUE)) ? 1u : 0u;
+  p.alpha = cfg->alpha;
+  p.eta0 = cfg->eta0;
+  p.eta1 = cfg->eta1;
+  p.nodetau0 = cfg->nodetau0;
+  p.nodekappa = cfg->nodekappa;
+  p.gamma_scale = cfg->gamma_scale;
+  p.thresh = cfg->conv_thresh;
+
+  uint32_t target = 512;
+  if (const char *s = getenv("TSAMD_GRID")) target = std::max(1, atoi(s));
+  target = std::min<uint32_t>(target, kMaxGrid);
+  uint32_t chunk = (p.npairs + target - 1) / target;
+  chunk = (chunk + kBlock - 1) / kBlock * kBlock;
+  p.chunk = chunk;
+  c->grid = (p.npairs + chunk - 1) / chunk;
+
+  CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
+  CREATE_TRY(hipMalloc((void **)&p.w, K * np * sizeof(double)));
+  CREATE_TRY(hipMalloc((void **)&p.gam, K * np * sizeof(double)));
+  CREATE_TRY(hipMalloc((void **)&p.cnt, np * sizeof(uint32_t)));
+  CREATE_TRY(hipMalloc((void **)&p.lam, L * K * 2 * sizeof(double)));
+  CREATE_TRY(hipMalloc((void **)&p.eb, L * K * 2 * sizeof(double)));
+  CREATE_TRY(hipMalloc((void **)&p.ctl, sizeof(Ctl)));
+  CREATE_TRY(hipMalloc((void **)&p.partials, (size_t)kMaxGrid * 2 * TSAMD_MAX_K * sizeof(double)));
+  c->sched_cap = 1024;
+  CREATE_TRY(hipMalloc((void **)&c->d_sched, c->sched_cap * sizeof(uint32_t)));
+  p.sched = c->d_sched;
+
+  CREATE_TRY(hipMemsetAsync(p.bed, 0x55, L * p.colstride, c->stream));  // all missing
+  CREATE_TRY(hipMemsetAsync(p.cnt, 0, np * sizeof(uint32_t), c->stream));
+  CREATE_TRY(hipMemsetAsync(p.ctl, 0, sizeof(Ctl), c->stream));
+  CREATE_TRY(hipMemsetAsync(p.partials, 0, (size_t)kMaxGrid * 2 * TSAMD_MAX_K * sizeof(double), c->stream));
+  hipLaunchKernelGGL(ts_fill_f64, dim3(1024), dim3(256), 0, c->stream, p.gam, K * np, 1.0, 1.0);
+  hipLaunchKernelGGL(ts_fill_f64, dim3(1024), dim3(256), 0, c->stream, p.w, K * np, 1.0, 1.0);
+  // init_lambda (src/snpsamplinge.cc:239-250): lambda = eta, Elogbeta = psi(eta_t) - psi(eta0 + eta1)
+  hipLaunchKernelGGL(ts_fill_f64, dim3(1024), dim3(256), 0, c->stream, p.lam, L * K * 2, cfg->eta0, cfg->eta1);
+  {
+    const uint64_t total = (uint64_t)L * K;
+    const uint32_t per = 1u << 20;  // locations per launch
+    for (uint64_t l0 = 0; l0 < L; l0 += per) {
+      const uint32_t nl = (uint32_t)std::min<uint64_t>(per, L - l0);
+      hipLaunchKernelGGL(ts_export_loc, dim3(((uint64_t)nl * K + 255) / 256), dim3(256), 0, c->stream, p.lam,
+                         (uint32_t)K, (uint32_t)l0, nl, 2, p.eb);
+    }
+    (void)total;
+  }
+  CREATE_TRY(hipGetLastError());
+  CREATE_TRY(hipStreamSynchronize(c->stream));
+#undef CREATE_TRY
+  *out = c;
+  return TSAMD_OK;
+}
+
+int tsamd_upload_bed(tsamd_ctx *c, const uint8_t *payload, uint64_t bytes_per_snp, uint32_t first_loc,
+                     uint32_t n_locs) {
+  CHECK_CTX(c);
+  if (!payload) return fail(c, TSAMD_EINVAL, "null payload");
+  if (bytes_per_snp != ((uint64_t)c->cfg.n + 3) / 4)
+    return fail(c, TSAMD_EINVAL, "bytes_per_snp %llu != ceil(n/4) = %llu", (unsigned long long)bytes_per_snp,
+                (unsigned long long)(((uint64_t)c->cfg.n + 3) / 4));
+  if (int rc = check_locs(c, first_loc, n_locs)) return rc;
+  HIP_TRY(c, hipSetDevice(c->dev));
+  const size_t cs = c->p.colstride;
+  const size_t src_off = c->n_begin / 4;
+  const size_t nbytes = ((size_t)c->n_local + 3) / 4;
+  const uint32_t tail = c->n_local & 3u;  // individuals in the last (partial) byte
+  const size_t batch = std::max<size_t>(1, (size_t)(32u << 20) / cs);
+  if (int rc = ensure_stage(c, std::min<size_t>(batch, n_locs) * cs)) return rc;
+  for (uint32_t j0 = 0; j0 < n_locs; j0 += (uint32_t)batch) {
+    const uint32_t nb = (uint32_t)std::min<size_t>(batch, n_locs - j0);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // staging buffer reuse
+    for (uint32_t j = 0; j < nb; ++j) {
+      uint8_t *dst = c->h_stage + (size_t)j * cs;
+      memcpy(dst, payload + (size_t)(j0 + j) * bytes_per_snp + src_off, nbytes);
+      if (tail) {  // neighbours' bits (or PLINK's zero padding) -> missing
+        const uint8_t keep = (uint8_t)((1u << (2 * tail)) - 1u);
+        dst[nbytes - 1] = (uint8_t)((dst[nbytes - 1] & keep) | (0x55u & ~keep));
+      }
+      memset(dst + nbytes, 0x55, cs - nbytes);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->p.bed + (size_t)(first_loc + j0) * cs, c->h_stage, (size_t)nb * cs,
+                              hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // a re-upload drops validation folds of those columns
+  for (auto it = c->held.lower_bound(first_loc); it != c->held.end() && it->first < first_loc + n_locs;)
+    it = c->held.erase(it);
+  return TSAMD_OK;
+}
+
+int tsamd_download_bed(tsamd_ctx *c, uint32_t loc, uint8_t *out, uint64_t out_bytes) {
+  CHECK_CTX(c);
+  if (int rc = check_locs(c, loc, 1)) return rc;
+  const size_t nbytes = ((size_t)c->n_local + 3) / 4;
+  if (!out || out_bytes < nbytes) return fail(c, TSAMD_EINVAL, "output buffer too small (%llu < %zu)",
+                                             (unsigned long long)out_bytes, nbytes);
+  HIP_TRY(c, hipSetDevice(c->dev));
+  HIP_TRY(c, hipMemcpyAsync(out, c->p.bed + (size_t)loc * c->p.colstride, nbytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TSAMD_OK;
+}
+
+int tsamd_set_heldout(tsamd_ctx *c, uint32_t loc, const uint32_t *indivs, uint32_t count) {
+  CHECK_CTX(c);
+  if (int rc = check_locs(c, loc, 1)) return rc;
+  if (count && !indivs) return fail(c, TSAMD_EINVAL, "null indivs");
+  HeldLoc &h = c->held[loc];
+  std::vector<uint32_t> ids;
+  for (uint32_t i = 0; i < count; ++i) {
+    if (indivs[i] >= c->cfg.n) return fail(c, TSAMD_EINVAL, "individual %u >= n", indivs[i]);
+    if (indivs[i] < c->n_begin || indivs[i] >= c->n_begin + c->n_local) continue;
+    const uint32_t lid = indivs[i] - c->n_begin;
+    if (std::find(h.local_ids.begin(), h.local_ids.end(), lid) != h.local_ids.end()) continue;
+    if (std::find(ids.begin(), ids.end(), lid) != ids.end()) continue;
+    ids.push_back(lid);
+  }
+  if (ids.empty()) {
+    if (h.local_ids.empty()) c->held.erase(loc);
+    return TSAMD_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->dev));
+  uint32_t *d_ids = nullptr;
+  uint8_t *d_orig = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&d_ids, ids.size() * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc((void **)&d_orig, ids.size()));
+  std::vector<uint8_t> orig(ids.size());
+  hipError_t e = hipMemcpyAsync(d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ts_heldout_fold, dim3((ids.size() + 255) / 256), dim3(256), 0, c->stream,
+                       c->p.bed + (size_t)loc * c->p.colstride, d_ids, (uint32_t)ids.size(), d_orig);
+    e = hipMemcpyAsync(orig.data(), d_orig, ids.size(), hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_ids);
+  hipFree(d_orig);
+  if (e != hipSuccess) return fail(c, TSAMD_EHIP, "set_heldout: %s", hipGetErrorString(e));
+  static const uint8_t dec[4] = {0, 3, 1, 2};
+  for (size_t i = 0; i < ids.size(); ++i) {
+    if (dec[orig[i]] == 3) continue;  // was already missing: stays missing, not a held-out entry
+    h.local_ids.push_back(ids[i]);
+    h.ytrue.push_back(dec[orig[i]]);
+  }
+  // keep ascending individual order (compute_likelihood iterates the map in that order)
+  std::vector<size_t> ord(h.local_ids.size());
+  for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+  std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return h.local_ids[a] < h.local_ids[b]; });
+  HeldLoc s;
+  for (size_t i : ord) {
+    s.local_ids.push_back(h.local_ids[i]);
+    s.ytrue.push_back(h.ytrue[i]);
+  }
+  h = std::move(s);
+  if (h.local_ids.empty()) c->held.erase(loc);
+  return TSAMD_OK;
+}
+
+int tsamd_set_gamma(tsamd_ctx *c, const double *gamma) {
+  CHECK_CTX(c);
+  if (!gamma) return fail(c, TSAMD_EINVAL, "null gamma");
+  for (size_t i = 0; i < (size_t)c->n_local * c->cfg.k; ++i)
+    if (!(gamma[i] > 0.0) || !std::isfinite(gamma[i])) return fail(c, TSAMD_EINVAL, "gamma[%zu] must be positive and finite", i);
+  HIP_TRY(c, hipSetDevice(c->dev));
+  if (int rc = upload_kmajor(c, gamma, c->p.gam, 1.0)) return rc;
+  dispatch_kt(c->kt, [&](auto KTc) {
+    constexpr int KT = decltype(KTc)::value;
+    hipLaunchKernelGGL((ts_refresh_w<KT>), dim3((c->p.npairs + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->p);
+    return 0;
+  });
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TSAMD_OK;
+}
+
+int tsamd_get_gamma(tsamd_ctx *c, double *out) {
+  CHECK_CTX(c);
+  if (!out) return fail(c, TSAMD_EINVAL, "null output");
+  HIP_TRY(c, hipSetDevice(c->dev));
+  return export_indiv(c, 0, out);
+}
+int tsamd_get_theta(tsamd_ctx *c, double *out) {
+  CHECK_CTX(c);
+  if (!out) return fail(c, TSAMD_EINVAL, "null output");
+  HIP_TRY(c, hipSetDevice(c->dev));
+  return export_indiv(c, 1, out);
+}
+int tsamd_get_elogtheta(tsamd_ctx *c, double *out) {
+  CHECK_CTX(c);
+  if (!out) return fail(c, TSAMD_EINVAL, "null output");
+  HIP_TRY(c, hipSetDevice(c->dev));
+  return export_indiv(c, 2, out);
+}
+
+int tsamd_set_counts(tsamd_ctx *c, const uint32_t *cn) {
+  CHECK_CTX(c);
+  if (!cn) return fail(c, TSAMD_EINVAL, "null counts");
+  HIP_TRY(c, hipSetDevice(c->dev));
+  HIP_TRY(c, hipMemcpyAsync(c->p.cnt, cn, (size_t)c->n_local * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TSAMD_OK;
+}
+int tsamd_get_counts(tsamd_ctx *c, uint32_t *cn) {
+  CHECK_CTX(c);
+  if (!cn) return fail(c, TSAMD_EINVAL, "null counts");
+  HIP_TRY(c, hipSetDevice(c->dev));
+  HIP_TRY(c, hipMemcpyAsync(cn, c->p.cnt, (size_t)c->n_local * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TSAMD_OK;
+}
+
+int tsamd_set_lambda(tsamd_ctx *c, uint32_t loc, const double *lambda) {
+  CHECK_CTX(c);
+  if (!lambda) return fail(c, TSAMD_EINVAL, "null lambda");
+  if (int rc = check_locs(c, loc, 1)) return rc;
+  const size_t J = 2 * (size_t)c->cfg.k;
+  for (size_t j = 0; j < J; ++j)
+    if (!(lambda[j] > 0.0) || !std::isfinite(lambda[j])) return fail(c, TSAMD_EINVAL, "lambda must be positive and finite");
+  HIP_TRY(c, hipSetDevice(c->dev));
+  HIP_TRY(c, hipMemcpyAsync(c->p.lam + (size_t)loc * J, lambda, J * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(ts_export_loc, dim3(1), dim3(256), 0, c->stream, c->p.lam, c->cfg.k, loc, 1u, 2, c->p.eb);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TSAMD_OK;
+}
+
+static int export_loc(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs, int mode, double *out) {
+  CHECK_CTX(c);
+  if (!out) return fail(c, TSAMD_EINVAL, "null output");
+  if (int rc = check_locs(c, first_loc, n_locs)) return rc;
+  if (n_locs == 0) return TSAMD_OK;
+  HIP_TRY(c, hipSetDevice(c->dev));
+  const size_t K = c->cfg.k;
+  const size_t per_loc = (mode == 0) ? K : 2 * K;
+  if (mode < 0) {  // raw lambda
+    HIP_TRY(c, hipMemcpyAsync(out, c->p.lam + (size_t)first_loc * 2 * K, (size_t)n_locs * 2 * K * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return TSAMD_OK;
+  }
+  const uint32_t per = 1u << 18;
+  double *d_out = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&d_out, (size_t)std::min(per, n_locs) * per_loc * sizeof(double)));
+  hipError_t e = hipSuccess;
+  for (uint32_t l0 = 0; l0 < n_locs && e == hipSuccess; l0 += per) {
+    const uint32_t nl = std::min(per, n_locs - l0);
+    hipLaunchKernelGGL(ts_export_loc, dim3(((uint64_t)nl * K + 255) / 256), dim3(256), 0, c->stream, c->p.lam,
+                       (uint32_t)K, first_loc + l0, nl, mode, d_out);
+    e = hipMemcpyAsync(out + (size_t)l0 * per_loc, d_out, (size_t)nl * per_loc * sizeof(double),
+                       hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  hipFree(d_out);
+  if (e != hipSuccess) return fail(c, TSAMD_EHIP, "export_loc: %s", hipGetErrorString(e));
+  return TSAMD_OK;
+}
+
+int tsamd_get_lambda(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs, double *out) {
+  return export_loc(c, first_loc, n_locs, -1, out);
+}
+int tsamd_get_ebeta(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs, double *out) {
+  return export_loc(c, first_loc, n_locs, 0, out);
+}
+int tsamd_get_elogbeta(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs, double *out) {
+  return export_loc(c, first_loc, n_locs, 1, out);
+}
+
+int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_mode) {
+  CHECK_CTX(c);
+  if (n == 0) return TSAMD_OK;
+  if (!locs) return fail(c, TSAMD_EINVAL, "null schedule");
+  if (c->cfg.world > 1 && !c->comm)
+    return fail(c, TSAMD_ECOMM, "context is shard %u of %u but tsamd_comm_init has not been called", c->cfg.rank,
+                c->cfg.world);
+  std::vector<uint32_t> ent(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (locs[i] >= c->cfg.l) return fail(c, TSAMD_EINVAL, "schedule[%u] = %u >= l", i, locs[i]);
+    ent[i] = locs[i] | (hol_mode ? 0x80000000u : 0u);
+  }
+  HIP_TRY(c, hipSetDevice(c->dev));
+  if (n > c->sched_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipFree(c->d_sched);
+    c->d_sched = nullptr;
+    c->sched_cap = 0;
+    uint32_t cap = 1024;
+    while (cap < n) cap *= 2;
+    HIP_TRY(c, hipMalloc((void **)&c->d_sched, (size_t)cap * sizeof(uint32_t)));
+    c->sched_cap = cap;
+    if (c->p.sched != c->d_sched) destroy_graph(c);  // captured kernel arguments hold the old pointer
+    c->p.sched = c->d_sched;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_sched, ent.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  c->keepalive.push_back(std::move(ent));  // until the next tsamd_synchronize
+  hipLaunchKernelGGL(ts_begin_schedule, dim3(1), dim3(1), 0, c->stream, c->p.ctl, n);
+  // everything that varies per SNP is read from device memory, so one captured
+  // sequence of kGraphSnps SNPs is replayed as often as needed; kernels past the
+  // end of the schedule return immediately.
+  const bool use_graph = !(c->cfg.flags & TSAMD_FLAG_NO_GRAPH) && !c->comm && !c->prof && n >= kGraphSnps;
+  if (use_graph) {
+    if (!c->graph_exec)
+      if (int rc = build_graph(c, kGraphSnps)) return rc;
+    for (uint32_t i = 0; i < n; i += kGraphSnps) HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
+    return TSAMD_OK;
+  }
+  for (uint32_t i = 0; i < n; ++i)
+    if (int rc = enqueue_snp(c)) return rc;
+  HIP_TRY(c, hipGetLastError());
+  return TSAMD_OK;
+}
+
+int tsamd_synchronize(tsamd_ctx *c) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->dev));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->keepalive.clear();
+  if (c->prof) {
+    for (uint32_t i = 0; i < c->n_ev_pass; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, c->ev_pass[2 * i], c->ev_pass[2 * i + 1]) == hipSuccess) {
+        c->prof_pass_ms += ms;
+        c->prof_pass_n++;
+      }
+    }
+    for (uint32_t i = 0; i < c->n_ev_first; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, c->ev_first[2 * i], c->ev_first[2 * i + 1]) == hipSuccess) {
+        c->prof_first_ms += ms;
+        c->prof_first_n++;
+      }
+    }
+    c->n_ev_pass = c->n_ev_first = 0;
+  }
+  return TSAMD_OK;
+}
+
+int tsamd_snp_update(tsamd_ctx *c, uint32_t loc, int hol_mode, uint32_t *inner_iters) {
+  CHECK_CTX(c);
+  if (int rc = tsamd_run_schedule(c, &loc, 1, hol_mode)) return rc;
+  if (int rc = tsamd_synchronize(c)) return rc;
+  if (inner_iters) {
+    HIP_TRY(c, hipMemcpy(inner_iters, &c->p.ctl->last_iters, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  }
+  return TSAMD_OK;
+}
+
+int tsamd_total_passes(tsamd_ctx *c, uint64_t *passes) {
+  CHECK_CTX(c);
+  if (!passes) return fail(c, TSAMD_EINVAL, "null output");
+  HIP_TRY(c, hipSetDevice(c->dev));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  unsigned long long v = 0;
+  HIP_TRY(c, hipMemcpy(&v, &c->p.ctl->total_passes, sizeof v, hipMemcpyDeviceToHost));
+  *passes = v;
+  return TSAMD_OK;
+}
+
+int tsamd_clear_pending(tsamd_ctx *c) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->dev));
+  HIP_TRY(c, hipMemsetAsync(&c->p.ctl->pend_do, 0, sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TSAMD_OK;
+}
+
+int tsamd_heldout_loglik(tsamd_ctx *c, uint32_t loc, double *sum, uint32_t *count) {
+  CHECK_CTX(c);
+  if (int rc = check_locs(c, loc, 1)) return rc;
+  if (sum) *sum = 0.0;
+  if (count) *count = 0;
+  auto it = c->held.find(loc);
+  if (it == c->held.end() || it->second.local_ids.empty()) return TSAMD_OK;
+  const HeldLoc &h = it->second;
+  const size_t m = h.local_ids.size();
+  HIP_TRY(c, hipSetDevice(c->dev));
+  uint32_t *d_ids = nullptr;
+  uint8_t *d_y = nullptr;
+  double *d_out = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&d_ids, m * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc((void **)&d_y, m));
+  HIP_TRY(c, hipMalloc((void **)&d_out, m * sizeof(double)));
+  std::vector<double> terms(m);
+  hipError_t e = hipMemcpyAsync(d_ids, h.local_ids.data(), m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_y, h.ytrue.data(), m, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ts_heldout_ll, dim3((m + 255) / 256), dim3(256), 0, c->stream, c->p.gam, c->npad, c->cfg.k,
+                       c->p.lam + (size_t)loc * 2 * c->cfg.k, d_ids, d_y, (uint32_t)m, d_out);
+    e = hipMemcpyAsync(terms.data(), d_out, m * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_ids);
+  hipFree(d_y);
+  hipFree(d_out);
+  if (e != hipSuccess) return fail(c, TSAMD_EHIP, "heldout_loglik: %s", hipGetErrorString(e));
+  double s = 0.0;
+  for (size_t i = 0; i < m; ++i) s += terms[i];  // ascending individual order, like the reference loop
+  if (sum) *sum = s;
+  if (count) *count = (uint32_t)m;
+  return TSAMD_OK;
+}
+
+int tsamd_comm_unique_id(uint8_t id[TSAMD_COMM_ID_BYTES]) {
+  if (!id) return fail(nullptr, TSAMD_EINVAL, "null id");
+  static_assert(sizeof(ncclUniqueId) == TSAMD_COMM_ID_BYTES, "ncclUniqueId size");
+  if (!g_rccl.load()) return fail(nullptr, TSAMD_ECOMM, "%s", g_rccl.error.c_str());
+  ncclUniqueId uid;
+  ncclResult_t r = g_rccl.GetUniqueId(&uid);
+  if (r != ncclSuccess) return fail(nullptr, TSAMD_ECOMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r));
+  memcpy(id, &uid, sizeof uid);
+  return TSAMD_OK;
+}
+
+int tsamd_comm_init(tsamd_ctx *c, const uint8_t id[TSAMD_COMM_ID_BYTES]) {
+  CHECK_CTX(c);
+  if (!id) return fail(c, TSAMD_EINVAL, "null id");
+  if (c->comm) return fail(c, TSAMD_EINVAL, "communicator already initialised");
+  if (!g_rccl.load()) return fail(c, TSAMD_ECOMM, "%s", g_rccl.error.c_str());
+  HIP_TRY(c, hipSetDevice(c->dev));
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm, (int)c->cfg.world, uid, (int)c->cfg.rank);
+  if (r != ncclSuccess) {
+    c->comm = nullptr;
+    return fail(c, TSAMD_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
+  }
+  c->p.multi = 1u;
+  destroy_graph(c);
+  return TSAMD_OK;
+}
+
+int tsamd_synth_genotypes(tsamd_ctx *c, const double *theta, const double *beta, uint32_t first_loc,
+                          uint32_t n_locs, uint64_t seed, double missing_rate) {
+  CHECK_CTX(c);
+  if (!theta || !beta) return fail(c, TSAMD_EINVAL, "null theta/beta");
+  if (int rc = check_locs(c, first_loc, n_locs)) return rc;
+  if (n_locs == 0) return TSAMD_OK;
+  HIP_TRY(c, hipSetDevice(c->dev));
+  const size_t K = c->cfg.k, np = c->npad;
+  double *d_theta = nullptr, *d_beta = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&d_theta, K * np * sizeof(double)));
+  int rc = upload_kmajor(c, theta, d_theta, 0.0);
+  const uint32_t per = 65535u * kSynthCols;
+  if (rc == TSAMD_OK) {
+    hipError_t e = hipMalloc((void **)&d_beta, (size_t)std::min(per, n_locs) * K * sizeof(double));
+    for (uint32_t j0 = 0; j0 < n_locs && e == hipSuccess; j0 += per) {
+      const uint32_t nl = std::min(per, n_locs - j0);
+      e = hipMemcpyAsync(d_beta, beta + (size_t)j0 * K, (size_t)nl * K * sizeof(double), hipMemcpyHostToDevice, c->stream);
+      if (e != hipSuccess) break;
+      dim3 grid((np / 4 + kBlock - 1) / kBlock, (nl + kSynthCols - 1) / kSynthCols);
+      hipLaunchKernelGGL(ts_synth, grid, dim3(kBlock), 0, c->stream, c->p.bed, c->p.colstride, d_theta, c->npad,
+                         c->n_local, c->n_begin, (uint32_t)K, d_beta, first_loc + j0, nl, seed, missing_rate);
+      e = hipStreamSynchronize(c->stream);
+    }
+    if (e != hipSuccess) rc = fail(c, TSAMD_EHIP, "synth_genotypes: %s", hipGetErrorString(e));
+  }
+  hipFree(d_theta);
+  hipFree(d_beta);
+  if (rc == TSAMD_OK)
+    for (auto it = c->held.lower_bound(first_loc); it != c->held.end() && it->first < first_loc + n_locs;)
+      it = c->held.erase(it);
+  return rc;
+}
+
+int tsamd_profile_enable(tsamd_ctx *c, int on) {
+  CHECK_CTX(c);
+  if (int rc = tsamd_synchronize(c)) return rc;
+  c->prof = on != 0;
+  c->prof_pass_n = c->prof_first_n = 0;
+  c->prof_pass_ms = c->prof_first_ms = 0;
+  c->n_ev_pass = c->n_ev_first = 0;
+  return TSAMD_OK;
+}
+
+int tsamd_profile_read(tsamd_ctx *c, uint64_t *pass_launches, double *pass_ms_total, uint64_t *first_launches,
+                       double *first_ms_total) {
+  CHECK_CTX(c);
+  if (int rc = tsamd_synchronize(c)) return rc;
+  if (pass_launches) *pass_launches = c->prof_pass_n;
+  if (pass_ms_total) *pass_ms_total = c->prof_pass_ms;
+  if (first_launches) *first_launches = c->prof_first_n;
+  if (first_ms_total) *first_ms_total = c->prof_first_ms;
+  return TSAMD_OK;
+}
+
+int tsamd_mem_info(tsamd_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->dev));
+  size_t f = 0, t = 0;
+  HIP_TRY(c, hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return TSAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// Device-side building blocks of the SNP-minibatch SVI engine (gfx950 only).
+//
+// Restates, for the GPU, the arithmetic of
+//   PhiRunnerE::update_phimom/update_phidad   src/snpsamplinge.hh:276-300
+//   D1Array<double>::logsum/lognormalize      src/matrix.hh:271-293
+//   PhiRunnerE::update_lambda_t               src/snpsamplinge.cc:742-759
+//   PhiRunnerE::update_gamma/estimate_theta   src/snpsamplinge.cc:695-740
+//   SNPSamplingE::update_lambda/estimate_beta src/snpsamplinge.cc:267-296
+// in the linear domain: with w[n,k] = exp(Elogtheta[n,k] - max_k) and
+// b[k,t] = exp(Elogbeta[loc,k,t]),  phi_t[n,k] = w[n,k] b[k,t] / sum_j w[n,j] b[j,t]
+// which is the reference's softmax without a per-pass exp/log.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tsamd.h"
+
+namespace tsamd {
+
+constexpr int kBlock = 256;       // threads per workgroup (4 waves)
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxGrid = 2048;    // upper bound on pass-kernel workgroups
+
+// Device-resident control block: everything the stream-ordered kernels need to
+// agree on without a host round trip.
+struct Ctl {
+  uint32_t cursor;     // index into the schedule of the NEXT SNP to start
+  uint32_t sched_len;  // entries in the schedule; kernels past the end are no-ops
+  uint32_t done;       // current SNP converged (mean |dlambda| < thresh)
+  uint32_t iters;      // passes executed for the current SNP
+  uint32_t ticket;     // arrival counter of the running pass kernel
+  uint32_t pend_do;    // previous SNP has a pending gamma step (it ran with hol_mode == 0)
+  uint32_t pend_loc;   // its location
+  uint32_t last_iters; // inner passes of the most recently finished SNP (for snp_update)
+  unsigned long long total_passes;
+  unsigned long long pad1;
+  double eb_stale[2 * TSAMD_MAX_K]; // exp(Elogbeta) used by the LAST executed pass of the pending SNP
+  double lt[2 * TSAMD_MAX_K];       // this shard's lambda_t (multi-GPU: all-reduce input)
+  double lt_sum[2 * TSAMD_MAX_K];   // all-reduced lambda_t
+};
+
+struct DevParams {
+  uint8_t *bed;        // [l][colstride] 2-bit PLINK codes, shard-local, padding = missing
+  uint64_t colstride;  // bytes per column (multiple of 64)
+  double *w;           // [K][npad]  exp(Elogtheta - rowmax)
+  double *gam;         // [K][npad]
+  uint32_t *cnt;       // [npad]     c_n
+  double *lam;         // [l][K][2]
+  double *eb;          // [l][K][2]  exp(Elogbeta)
+  Ctl *ctl;
+  double *partials;    // [grid][2K]
+  const uint32_t *sched; // entries: loc | hol_mode << 31
+  uint32_t npad;       // padded individuals (multiple of 512)
+  uint32_t npairs;     // npad / 2
+  uint32_t chunk;      // pairs per workgroup (multiple of 256)
+  uint32_t K;
+  uint32_t max_inner;
+  uint32_t multi;      // 1: leave lambda_t in ctl->lt for the all-reduce, epilogue runs as its own kernel
+  double alpha, eta0, eta1, nodetau0, nodekappa, gamma_scale, thresh;
+};
+
+// ---------------------------------------------------------------------------
+// psi(x), x > 0.  Branch-free: shift by 10 with one rational accumulation
+// (sum_{i<10} 1/(x+i) = P'(x)/P(x)), then the asymptotic series at x+10 >= 10
+// (terms B2n/(2n z^2n), n = 1..7; the next term is < 5e-17 there).
+// Restates what the reference gets from gsl_sf_psi (src/lib.hh:29-33,
+// src/snpsamplinge.cc:292-294, :734-737).
+__device__ __forceinline__ double digamma(double x) {
+  const bool big = x >= 1.0e8;       // P(x) would not overflow until ~1e30, but nothing is gained
+  const double xs = big ? 1.0 : x;
+  double num = 0.0, den = 1.0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const double xi = xs + (double)i;
+    num = fma(num, xi, den);
+    den *= xi;
+  }
+  const double z = big ? x : x + 10.0;
+  const double rz = 1.0 / z;
+  const double f = rz * rz;
+  double t = -1.0 / 12.0;
+  t = fma(f, t, 691.0 / 32760.0);
+  t = fma(f, t, -1.0 / 132.0);
+  t = fma(f, t, 1.0 / 240.0);
+  t = fma(f, t, -1.0 / 252.0);
+  t = fma(f, t, 1.0 / 120.0);
+  t = fma(f, t, -1.0 / 12.0);
+  const double tail = log(z) - 0.5 * rz + f * t;
+  return big ? tail : tail - num / den;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// PLINK 2-bit code -> (weight of the "mom" copy = y, weight of the "dad" copy = 2 - y);
+// 01 (missing, or held out) -> (0, 0).  src/snp.cc:203-216, src/snpsamplinge.cc:755-756.
+__device__ __forceinline__ void code_weights(uint32_t c, double &mom, double &dad, bool &ok) {
+  const uint32_t hi = c >> 1, lo = c & 1u;
+  ok = !(hi == 0u && lo == 1u);
+  const uint32_t y = hi * (1u + lo);
+  mom = (double)y;
+  dad = ok ? (double)(2u - y) : 0.0;
+}
+
+// agent-scope accessors for data handed between workgroups inside one launch
+__device__ __forceinline__ void st_agent(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace tsamd
