@@ -62,6 +62,7 @@ typedef struct tsamd_config {
 } tsamd_config;
 
 #define TSAMD_FLAG_SPLIT_EPILOGUE 1u /* run the K x 2 epilogue as its own kernel even on one GPU */
+#define TSAMD_FLAG_FINISH_KERNEL 4u  /* add the partial rows up in a follow-up kernel instead of the in-kernel ticket */
 #define TSAMD_FLAG_NO_GRAPH 2u       /* tsamd_run_schedule launches eagerly instead of replaying a hipGraph */
 
 int tsamd_abi_version(void);

@@ -1,16 +1,26 @@
-"""Builds libtsamd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree."""
+"""Builds libtsamd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+The K-specialised kernels are compiled as one translation unit per K
+(csrc/tsamd_inst.hip with -DTSAMD_K=k), in parallel; objects are cached under
+terastructure_amd/lib/obj and rebuilt when a source they include changes.
+"""
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libtsamd.so")
-SOURCES = ["tsamd.hip"]
-DEPS = ["tsamd.hip", "tsamd_kernels.h", "tsamd_device.h", os.path.join(ROOT, "include", "tsamd.h")]
+MAX_K = 32
+HEADERS = [os.path.join(CSRC, "tsamd_kernels.h"), os.path.join(CSRC, "tsamd_generic_kernels.h"), os.path.join(CSRC, "tsamd_device.h"),
+           os.path.join(ROOT, "include", "tsamd.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
 def _hipcc():
@@ -20,26 +30,52 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+def _units():
+    """(object path, source path, extra flags)"""
+    units = [(os.path.join(OBJ_DIR, "tsamd.o"), os.path.join(CSRC, "tsamd.hip"), [])]
+    for k in range(1, MAX_K + 1):
+        units.append((os.path.join(OBJ_DIR, f"inst_k{k}.o"), os.path.join(CSRC, "tsamd_inst.hip"),
+                      [f"-DTSAMD_K={k}"]))
+    return units
+
+
+def _stale(obj, src):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src] + HEADERS)
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    for d in DEPS:
-        path = d if os.path.isabs(d) else os.path.join(CSRC, d)
-        if os.path.getmtime(path) > t:
-            return True
-    return False
+    return any(_stale(o, s) or os.path.getmtime(o) > t for o, s, _ in _units())
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, jobs=None):
     if not force and not needs_build():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-           "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    todo = [(o, s, x) for o, s, x in _units() if force or _stale(o, s)]
+
+    def compile_one(unit):
+        obj, src, extra = unit
+        cmd = [hipcc, "-c"] + FLAGS + extra + ["-o", obj, src]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout)
+        return obj
+
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
+        print(f"[tsamd build] compiling {len(todo)} unit(s) with {jobs} job(s) for gfx950", file=sys.stderr)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [o for o, _, _ in _units()] + ["-ldl"]
+    if verbose:
+        print("[tsamd build] linking " + LIB_PATH, file=sys.stderr)
     subprocess.check_call(cmd)
     return LIB_PATH
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "tsamd.h"
+#include "tsamd_generic_kernels.h"
 #include "tsamd_kernels.h"
 
 using namespace tsamd;
@@ -82,8 +83,7 @@ struct tsamd_ctx {
   int dev = 0;
   hipStream_t stream = nullptr;
   uint32_t n_begin = 0, n_local = 0, npad = 0;
-  int kt = 0;
-  uint32_t grid = 0;
+  uint32_t grid = 0, block = 256, grid_first = 0;  // plain-pass and first-pass launch geometry
   DevParams p{};
   uint32_t *d_sched = nullptr;
   uint32_t sched_cap = 0;
@@ -91,6 +91,7 @@ struct tsamd_ctx {
   size_t stage_bytes = 0;
   std::map<uint32_t, HeldLoc> held;
   ncclComm_t comm = nullptr;
+  bool split = false;  // lambda_t leaves the pass via ctl->lt and the epilogue is its own kernel
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev_pass, ev_first;  // start/stop pairs
@@ -131,28 +132,18 @@ int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
 #define CHECK_CTX(ctx) \
   if (!(ctx)) return TSAMD_EINVAL
 
-int pick_kt(uint32_t k) {
-  static const int kts[] = {2, 3, 4, 6, 8, 12, 16, 20, 24, 32};
-  for (int v : kts)
-    if ((int)k <= v) return v;
-  return 0;
+// launchers of the K-specialised kernels, one per translation unit (tsamd_inst.hip)
+#define TSAMD_DECL(k) void launch_k##k(int, uint32_t, uint32_t, hipStream_t, const DevParams &);
+#define TSAMD_ALL_K(X)                                                                             \
+  X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)     \
+  X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+}  // namespace
+namespace tsamd {
+TSAMD_ALL_K(TSAMD_DECL)
 }
-
-template <typename F>
-auto dispatch_kt(int kt, F &&f) {
-  switch (kt) {
-    case 2: return f(std::integral_constant<int, 2>{});
-    case 3: return f(std::integral_constant<int, 3>{});
-    case 4: return f(std::integral_constant<int, 4>{});
-    case 6: return f(std::integral_constant<int, 6>{});
-    case 8: return f(std::integral_constant<int, 8>{});
-    case 12: return f(std::integral_constant<int, 12>{});
-    case 16: return f(std::integral_constant<int, 16>{});
-    case 20: return f(std::integral_constant<int, 20>{});
-    case 24: return f(std::integral_constant<int, 24>{});
-    default: return f(std::integral_constant<int, 32>{});
-  }
-}
+namespace {
+#define TSAMD_ENTRY(k) tsamd::launch_k##k,
+const LaunchFn kLaunchers[TSAMD_MAX_K + 1] = {nullptr, TSAMD_ALL_K(TSAMD_ENTRY)};
 
 __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -160,14 +151,10 @@ __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
 }
 
 void launch_pass(tsamd_ctx *c, bool first) {
-  dispatch_kt(c->kt, [&](auto KTc) {
-    constexpr int KT = decltype(KTc)::value;
-    if (first)
-      hipLaunchKernelGGL((ts_pass<KT, true>), dim3(c->grid), dim3(kBlock), 0, c->stream, c->p);
-    else
-      hipLaunchKernelGGL((ts_pass<KT, false>), dim3(c->grid), dim3(kBlock), 0, c->stream, c->p);
-    return 0;
-  });
+  if (first)
+    kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, 256, c->stream, c->p);
+  else
+    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p);
 }
 
 void launch_epilogue(tsamd_ctx *c, bool first) {
@@ -177,9 +164,10 @@ void launch_epilogue(tsamd_ctx *c, bool first) {
     hipLaunchKernelGGL((ts_epilogue<false>), dim3(1), dim3(64), 0, c->stream, c->p);
 }
 
-bool split_epilogue(const tsamd_ctx *c) { return c->p.multi != 0; }
-
-// one pass = pass kernel [+ all-reduce] [+ epilogue kernel]
+// one pass = pass kernel [+ finish kernel] [+ all-reduce + epilogue kernel]
+//   tail 0, one GPU : ts_pass (ticket: last workgroup reduces and runs the epilogue)
+//   tail 2, one GPU : ts_pass, ts_finish (reduce + epilogue after the kernel boundary)
+//   sharded / split : ts_pass [, ts_finish] -> ctl->lt, all-reduce -> ctl->lt_sum, ts_epilogue
 int enqueue_pass(tsamd_ctx *c, bool first) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
@@ -201,7 +189,14 @@ int enqueue_pass(tsamd_ctx *c, bool first) {
   }
   launch_pass(c, first);
   if (e1) HIP_TRY(c, hipEventRecord(e1, c->stream));
-  if (split_epilogue(c)) {
+  const uint32_t G = first ? c->grid_first : c->grid;
+  if (c->p.tail == 2u) {
+    if (first)
+      hipLaunchKernelGGL((ts_finish<true>), dim3(1), dim3(256), 0, c->stream, c->p, G, c->split ? 1u : 0u);
+    else
+      hipLaunchKernelGGL((ts_finish<false>), dim3(1), dim3(256), 0, c->stream, c->p, G, c->split ? 1u : 0u);
+  }
+  if (c->split) {
     if (c->comm) {
       ncclResult_t r = g_rccl.AllReduce(c->p.ctl->lt, c->p.ctl->lt_sum, 2 * c->cfg.k, ncclDouble, ncclSum, c->comm,
                                         c->stream);
@@ -378,7 +373,6 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   c->n_begin = b;
   c->n_local = cnt;
   c->npad = (cnt + 511u) / 512u * 512u;
-  c->kt = pick_kt(cfg->k);
 #define CREATE_TRY(expr)                                                                          \
   do {                                                                                            \
     hipError_t e_ = (expr);                                                                       \
@@ -399,7 +393,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   p.npairs = c->npad / 2;
   p.K = cfg->k;
   p.max_inner = cfg->max_inner;
-  p.multi = (cfg->world > 1 || (cfg->flags & TSAMD_FLAG_SPLIT_EPILOGUE)) ? 1u : 0u;
+  c->split = cfg->world > 1 || (cfg->flags & TSAMD_FLAG_SPLIT_EPILOGUE);
   p.alpha = cfg->alpha;
   p.eta0 = cfg->eta0;
   p.eta1 = cfg->eta1;
@@ -408,13 +402,31 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   p.gamma_scale = cfg->gamma_scale;
   p.thresh = cfg->conv_thresh;
 
-  uint32_t target = 512;
-  if (const char *s = getenv("TSAMD_GRID")) target = std::max(1, atoi(s));
-  target = std::min<uint32_t>(target, kMaxGrid);
-  uint32_t chunk = (p.npairs + target - 1) / target;
-  chunk = (chunk + kBlock - 1) / kBlock * kBlock;
-  p.chunk = chunk;
-  c->grid = (p.npairs + chunk - 1) / chunk;
+  // Launch geometry.  The pass kernel is a streaming reduction: enough waves per CU to
+  // cover HBM latency, but few workgroups, because every workgroup costs one arrival on
+  // the ticket and one partial row for the last workgroup to add up.
+  auto env_u32 = [](const char *name, uint32_t dflt) {
+    const char *s = getenv(name);
+    return (s && *s) ? (uint32_t)std::max(0, atoi(s)) : dflt;
+  };
+  uint32_t block = (cfg->k <= 8) ? 1024u : (cfg->k <= 16) ? 512u : 256u;
+  while (block > 256u && p.npairs < 64u * block) block /= 2;  // small shards: fewer, smaller groups
+  block = env_u32("TSAMD_BLOCK", block);
+  if (block != 256u && block != 512u && block != 1024u) block = 256u;
+  auto geometry = [&](uint32_t blk, uint32_t target, uint32_t &chunk, uint32_t &grid) {
+    target = std::min<uint32_t>(std::max<uint32_t>(target, 1u), kMaxGrid);
+    chunk = (p.npairs + target - 1) / target;
+    chunk = (chunk + blk - 1) / blk * blk;
+    grid = (p.npairs + chunk - 1) / chunk;
+  };
+  c->block = block;
+  {
+    const uint32_t dflt = (cfg->flags & TSAMD_FLAG_FINISH_KERNEL) ? 2u : 0u;
+    const uint32_t mode = env_u32("TSAMD_TAIL", dflt);
+    p.tail = (mode == 2u) ? 2u : (c->split ? 1u : 0u);
+  }
+  geometry(block, env_u32("TSAMD_GRID", 256), p.chunk, c->grid);
+  geometry(256, env_u32("TSAMD_GRID_FIRST", 512), p.chunk_first, c->grid_first);
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
   CREATE_TRY(hipMalloc((void **)&p.w, K * np * sizeof(double)));
@@ -563,11 +575,7 @@ int tsamd_set_gamma(tsamd_ctx *c, const double *gamma) {
     if (!(gamma[i] > 0.0) || !std::isfinite(gamma[i])) return fail(c, TSAMD_EINVAL, "gamma[%zu] must be positive and finite", i);
   HIP_TRY(c, hipSetDevice(c->dev));
   if (int rc = upload_kmajor(c, gamma, c->p.gam, 1.0)) return rc;
-  dispatch_kt(c->kt, [&](auto KTc) {
-    constexpr int KT = decltype(KTc)::value;
-    hipLaunchKernelGGL((ts_refresh_w<KT>), dim3((c->p.npairs + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->p);
-    return 0;
-  });
+  kLaunchers[c->cfg.k](kLaunchRefresh, 0, 0, c->stream, c->p);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSAMD_OK;
@@ -822,7 +830,8 @@ int tsamd_comm_init(tsamd_ctx *c, const uint8_t id[TSAMD_COMM_ID_BYTES]) {
     c->comm = nullptr;
     return fail(c, TSAMD_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
   }
-  c->p.multi = 1u;
+  c->split = true;
+  if (c->p.tail == 0u) c->p.tail = 1u;
   destroy_graph(c);
   return TSAMD_OK;
 }

@@ -17,8 +17,7 @@
 
 namespace tsamd {
 
-constexpr int kBlock = 256;       // threads per workgroup (4 waves)
-constexpr int kWaves = kBlock / 64;
+constexpr int kBlock = 256;       // threads per workgroup of the generic kernels
 constexpr int kMaxGrid = 2048;    // upper bound on pass-kernel workgroups
 
 // Device-resident control block: everything the stream-ordered kernels need to
@@ -52,10 +51,13 @@ struct DevParams {
   const uint32_t *sched; // entries: loc | hol_mode << 31
   uint32_t npad;       // padded individuals (multiple of 512)
   uint32_t npairs;     // npad / 2
-  uint32_t chunk;      // pairs per workgroup (multiple of 256)
+  uint32_t chunk;      // pairs per workgroup of the plain pass kernel (multiple of its block size)
+  uint32_t chunk_first; // same for the first-pass (gamma-fused) kernel
   uint32_t K;
   uint32_t max_inner;
-  uint32_t multi;      // 1: leave lambda_t in ctl->lt for the all-reduce, epilogue runs as its own kernel
+  uint32_t tail;       // how a pass ends: 0 = ticket, last workgroup reduces + runs the epilogue;
+                       // 1 = ticket, last workgroup leaves lambda_t in ctl->lt (all-reduce follows);
+                       // 2 = nothing: the ts_finish kernel that follows adds the partial rows up
   double alpha, eta0, eta1, nodetau0, nodekappa, gamma_scale, thresh;
 };
 
@@ -89,11 +91,68 @@ __device__ __forceinline__ double digamma(double x) {
   return big ? tail : tail - num / den;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+// v from lane (lane ^ OFF).  OFF < 32: ds_swizzle bit mode (no address register, no
+// memory access); OFF == 32: ds_bpermute.
+template <int OFF>
+__device__ __forceinline__ double xor_lane(double v) {
+  const unsigned long long u = __double_as_longlong(v);
+  int lo = (int)(uint32_t)u, hi = (int)(uint32_t)(u >> 32);
+  if constexpr (OFF < 32) {
+    constexpr int pattern = (OFF << 10) | 0x1f;  // and_mask 0x1f, or_mask 0, xor_mask OFF
+    lo = __builtin_amdgcn_ds_swizzle(lo, pattern);
+    hi = __builtin_amdgcn_ds_swizzle(hi, pattern);
+  } else {
+    const int addr = (int)((__lane_id() ^ 32u) << 2);
+    lo = __builtin_amdgcn_ds_bpermute(addr, lo);
+    hi = __builtin_amdgcn_ds_bpermute(addr, hi);
+  }
+  return __longlong_as_double(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
 }
+
+// Sum NV per-lane values across the 64 lanes of a wave with a halving butterfly: at
+// each step a lane keeps half of its values and trades the other half with its partner,
+// so the traffic is NV + NV/2 + ... instead of 6 * NV shuffles.  NV is padded to a power
+// of two P <= 64.  On return v[0] of lane l holds the wave total of value
+// wave_sum_slot<NV>(l) (all lanes sharing that slot hold the same bits).  Fixed order.
+template <int NV>
+struct WaveFold {
+  static constexpr int P = NV <= 1 ? 1 : NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : NV <= 32 ? 32 : 64;
+  // value index owned by lane l after fold(): bit (5 - s) of the lane selects the half at step s
+  __device__ static __forceinline__ int slot(uint32_t lane) {
+    int idx = 0, h = P;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      if (h == 1) break;
+      h >>= 1;
+      if ((lane >> (5 - s)) & 1u) idx += h;
+    }
+    return idx;
+  }
+  template <int S, int H>
+  __device__ static __forceinline__ void step(double (&v)[P], uint32_t lane) {
+    if constexpr (S < 6) {
+      constexpr int off = 32 >> S;
+      if constexpr (H > 1) {
+        constexpr int h = H / 2;
+        const bool up = (lane & (uint32_t)off) != 0u;  // upper partner keeps the upper half
+#pragma unroll
+        for (int i = 0; i < h; ++i) {
+          const double keep = up ? v[i + h] : v[i];
+          const double send = up ? v[i] : v[i + h];
+          v[i] = keep + xor_lane<off>(send);
+        }
+        step<S + 1, h>(v, lane);
+      } else {
+        v[0] += xor_lane<off>(v[0]);
+        step<S + 1, 1>(v, lane);
+      }
+    }
+  }
+  __device__ static __forceinline__ double fold(double (&v)[P], uint32_t lane) {
+    step<0, P>(v, lane);
+    return v[0];
+  }
+};
 
 // PLINK 2-bit code -> (weight of the "mom" copy = y, weight of the "dad" copy = 2 - y);
 // 01 (missing, or held out) -> (0, 0).  src/snp.cc:203-216, src/snpsamplinge.cc:755-756.
@@ -103,6 +162,14 @@ __device__ __forceinline__ void code_weights(uint32_t c, double &mom, double &da
   const uint32_t y = hi * (1u + lo);
   mom = (double)y;
   dad = ok ? (double)(2u - y) : 0.0;
+}
+
+// wave-uniform double -> scalar registers (frees VGPRs; v_fma_f64 takes one SGPR pair)
+__device__ __forceinline__ double uniform_f64(double v) {
+  const unsigned long long u = __double_as_longlong(v);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
 // agent-scope accessors for data handed between workgroups inside one launch

@@ -1,0 +1,149 @@
+// Kernels that do not depend on K at compile time (accessors, validation mask,
+// synthetic data).  Included by tsamd.hip only.
+#pragma once
+#include "tsamd_device.h"
+
+namespace tsamd {
+
+// mode 0: gamma, 1: theta = gamma / sum, 2: Elogtheta = psi(gamma) - psi(sum)
+// (estimate_all_theta src/snpsamplinge.cc:595-609, set_dir_exp src/lib.hh:19-35);
+// out is row-major [n_out][K]; rows = list of local individual ids or NULL for 0..n_out-1.
+__global__ void ts_export_indiv(const double *gam, uint32_t npad, uint32_t K, uint32_t n_out,
+                                const uint32_t *rows, int mode, double *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const uint32_t n = rows ? rows[i] : i;
+  double s = 0.0;
+  for (uint32_t k = 0; k < K; ++k) s += gam[(size_t)k * npad + n];
+  const double ps = (mode == 2) ? digamma(s) : 0.0;
+  for (uint32_t k = 0; k < K; ++k) {
+    const double g = gam[(size_t)k * npad + n];
+    out[(size_t)i * K + k] = (mode == 0) ? g : (mode == 1) ? g / s : digamma(g) - ps;
+  }
+}
+
+// mode 0: Ebeta[loc][k] = l0/(l0+l1); mode 1: Elogbeta[loc][k][t]; mode 2: exp(Elogbeta) into eb
+// (estimate_beta, src/snpsamplinge.cc:279-296)
+__global__ void ts_export_loc(const double *lam, uint32_t K, uint32_t first_loc, uint32_t n_locs, int mode,
+                              double *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_locs * K) return;
+  const uint32_t loc = first_loc + i / K, k = i % K;
+  const double l0 = lam[((size_t)loc * K + k) * 2], l1 = lam[((size_t)loc * K + k) * 2 + 1];
+  double s = 0.0;
+  s += l0;
+  s += l1;
+  if (mode == 0) {
+    out[i] = l0 / s;
+  } else {
+    const double ps = digamma(s);
+    const double e0 = digamma(l0) - ps, e1 = digamma(l1) - ps;
+    double *o = (mode == 1) ? out + (size_t)i * 2 : out + ((size_t)loc * K + k) * 2;
+    o[0] = (mode == 1) ? e0 : exp(e0);
+    o[1] = (mode == 1) ? e1 : exp(e1);
+  }
+}
+
+// fold validation entries into the column as "missing" (01) and return the true codes
+__global__ void ts_heldout_fold(uint8_t *col, const uint32_t *local_ids, uint32_t count, uint8_t *orig) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t n = local_ids[i];
+  uint32_t *word = reinterpret_cast<uint32_t *>(col) + (n >> 4);
+  const uint32_t sh = 2u * (n & 15u);
+  const uint32_t old = atomicOr(word, 1u << sh);
+  atomicAnd(word, ~(2u << sh));
+  orig[i] = (uint8_t)((old >> sh) & 3u);
+}
+
+// per-entry held-out log-likelihood term (snp_likelihood, src/snpsamplinge.hh:336-360)
+__global__ void ts_heldout_ll(const double *gam, uint32_t npad, uint32_t K, const double *lam_loc,
+                              const uint32_t *local_ids, const uint8_t *ytrue, uint32_t count, double *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t n = local_ids[i];
+  double s = 0.0;
+  for (uint32_t k = 0; k < K; ++k) s += gam[(size_t)k * npad + n];
+  double q = 0.0;
+  for (uint32_t k = 0; k < K; ++k) {
+    const double l0 = lam_loc[2 * k], l1 = lam_loc[2 * k + 1];
+    double ls = 0.0;
+    ls += l0;
+    ls += l1;
+    q += (l0 / ls) * (gam[(size_t)k * npad + n] / s);
+  }
+  const int x = ytrue[i];
+  const double v = (x == 1) ? 2.0 : 1.0;  // 2!/(x!(2-x)!)
+  double sum = v * pow(q, (double)x) * pow(1.0 - q, (double)(2 - x));
+  if (sum < 1e-30) sum = 1e-30;
+  out[i] = log(sum);
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic Pritchard-Stephens-Donnelly genotypes: one thread makes one
+// column byte (4 individuals) for CT consecutive columns.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+constexpr int kSynthCols = 8;
+
+__global__ __launch_bounds__(kBlock) void ts_synth(uint8_t *bed, uint64_t colstride, const double *theta_kmajor,
+                                                  uint32_t npad, uint32_t n_local, uint32_t n_begin, uint32_t K,
+                                                  const double *beta, uint32_t first_loc, uint32_t n_locs,
+                                                  uint64_t seed, double missing_rate) {
+  __shared__ double s_beta[kSynthCols * TSAMD_MAX_K];
+  const uint32_t q = blockIdx.x * kBlock + threadIdx.x;  // quad of individuals
+  const uint32_t c0 = blockIdx.y * kSynthCols;
+  const uint32_t nc = min((uint32_t)kSynthCols, n_locs - c0);
+  for (uint32_t t = threadIdx.x; t < nc * K; t += kBlock) s_beta[t] = beta[(size_t)c0 * K + t];
+  __syncthreads();
+  if (q >= npad / 4) return;
+  double pr[kSynthCols][4];
+#pragma unroll
+  for (int c = 0; c < kSynthCols; ++c)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pr[c][u] = 0.0;
+  for (uint32_t k = 0; k < K; ++k) {
+    const double2 t01 = reinterpret_cast<const double2 *>(theta_kmajor + (size_t)k * npad)[2 * q];
+    const double2 t23 = reinterpret_cast<const double2 *>(theta_kmajor + (size_t)k * npad)[2 * q + 1];
+#pragma unroll
+    for (int c = 0; c < kSynthCols; ++c) {
+      const double b = (c < (int)nc) ? s_beta[c * K + k] : 0.0;
+      pr[c][0] = fma(t01.x, b, pr[c][0]);
+      pr[c][1] = fma(t01.y, b, pr[c][1]);
+      pr[c][2] = fma(t23.x, b, pr[c][2]);
+      pr[c][3] = fma(t23.y, b, pr[c][3]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < kSynthCols; ++c) {
+    if (c >= (int)nc) break;
+    const uint32_t loc = first_loc + c0 + c;
+    uint32_t byte = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t nl = 4 * q + u;
+      uint32_t code = 1u;  // padding individuals are missing
+      if (nl < n_local) {
+        const uint64_t key = ((uint64_t)loc << 32) | (uint64_t)(n_begin + nl);
+        const uint64_t h = mix64(mix64(seed) ^ key);
+        const double u1 = (double)(uint32_t)(h >> 32) * (1.0 / 4294967296.0);
+        const double u2 = (double)(uint32_t)h * (1.0 / 4294967296.0);
+        const uint32_t y = (u1 < pr[c][u] ? 1u : 0u) + (u2 < pr[c][u] ? 1u : 0u);
+        code = (y == 0u) ? 0u : (y == 1u) ? 2u : 3u;
+        if (missing_rate > 0.0) {
+          const uint64_t h2 = mix64(h);
+          if ((double)(uint32_t)(h2 >> 32) * (1.0 / 4294967296.0) < missing_rate) code = 1u;
+        }
+      }
+      byte |= code << (2 * u);
+    }
+    bed[(size_t)loc * colstride + q] = (uint8_t)byte;
+  }
+}
+
+}  // namespace tsamd

@@ -1,0 +1,35 @@
+// One instantiation unit of the K-specialised kernels: compiled once per K with
+// -DTSAMD_K=<k> (terastructure_amd/build.py), so the builds run in parallel and the
+// kernels see K as a compile-time constant.
+#include "tsamd_kernels.h"
+
+#ifndef TSAMD_K
+#error "compile with -DTSAMD_K=<populations>"
+#endif
+
+#define TSAMD_CAT2(a, b) a##b
+#define TSAMD_CAT(a, b) TSAMD_CAT2(a, b)
+
+namespace tsamd {
+
+void TSAMD_CAT(launch_k, TSAMD_K)(int which, uint32_t grid, uint32_t block, hipStream_t stream, const DevParams &p) {
+  constexpr int K = TSAMD_K;
+  switch (which) {
+    case kLaunchPass:
+      if (block == 1024)
+        hipLaunchKernelGGL((ts_pass<K, false, 1024>), dim3(grid), dim3(1024), 0, stream, p);
+      else if (block == 512)
+        hipLaunchKernelGGL((ts_pass<K, false, 512>), dim3(grid), dim3(512), 0, stream, p);
+      else
+        hipLaunchKernelGGL((ts_pass<K, false, 256>), dim3(grid), dim3(256), 0, stream, p);
+      break;
+    case kLaunchFirst:
+      hipLaunchKernelGGL((ts_pass<K, true, 256>), dim3(grid), dim3(256), 0, stream, p);
+      break;
+    default:
+      hipLaunchKernelGGL((ts_refresh_w<K>), dim3((p.npairs + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, p);
+      break;
+  }
+}
+
+}  // namespace tsamd

@@ -66,18 +66,16 @@ __device__ __forceinline__ void epilogue_block(const DevParams &p, Ctl *ctl, uin
 // w[k] = exp(psi(g[k]) - max_j psi(g[j])): Elogtheta up to a per-individual constant,
 // which cancels in phi (estimate_theta, src/snpsamplinge.cc:721-740).
 template <int KT>
-__device__ __forceinline__ void gamma_to_w(const double (&g)[KT], double (&w)[KT], uint32_t K) {
+__device__ __forceinline__ void gamma_to_w(const double (&g)[KT], double (&w)[KT]) {
   double ps[KT];
   double mx = -1.0e300;
 #pragma unroll
-  for (int k = 0; k < KT; ++k)
-    if (k < (int)K) {
-      ps[k] = digamma(g[k]);
-      mx = fmax(mx, ps[k]);
-    }
+  for (int k = 0; k < KT; ++k) {
+    ps[k] = digamma(g[k]);
+    mx = fmax(mx, ps[k]);
+  }
 #pragma unroll
-  for (int k = 0; k < KT; ++k)
-    if (k < (int)K) w[k] = exp(ps[k] - mx);
+  for (int k = 0; k < KT; ++k) w[k] = exp(ps[k] - mx);
 }
 
 // SVI step for one individual (update_gamma + update_rho_indiv,
@@ -89,36 +87,39 @@ __device__ __forceinline__ void gamma_step_one(double (&g)[KT], const double (&w
                                                const DevParams &p) {
   double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-  for (int k = 0; k < KT; ++k)
-    if (k < (int)p.K) {
-      s0 = fma(w[k], sb0[k], s0);
-      s1 = fma(w[k], sb1[k], s1);
-    }
+  for (int k = 0; k < KT; ++k) {
+    s0 = fma(w[k], sb0[k], s0);
+    s1 = fma(w[k], sb1[k], s1);
+  }
   const double base = p.nodetau0 + (double)c;
   const double rho = (p.nodekappa == 0.5) ? 1.0 / sqrt(base) : pow(base, -p.nodekappa);
   c += 1u;
   const double c0 = mom / s0, c1 = dad / s1;
 #pragma unroll
-  for (int k = 0; k < KT; ++k)
-    if (k < (int)p.K) {
-      const double e = c0 * (w[k] * sb0[k]) + c1 * (w[k] * sb1[k]);  // y*phi_mom + (2-y)*phi_dad
-      g[k] += rho * (p.alpha + p.gamma_scale * e - g[k]);
-    }
+  for (int k = 0; k < KT; ++k) {
+    const double e = c0 * (w[k] * sb0[k]) + c1 * (w[k] * sb1[k]);  // y*phi_mom + (2-y)*phi_dad
+    g[k] += rho * (p.alpha + p.gamma_scale * e - g[k]);
+  }
 }
 
-template <int KT, bool FIRST>
-__global__ __launch_bounds__(kBlock) void ts_pass(DevParams p) {
+// One inner pass for the current SNP.  KT == K exactly (one instantiation per K), so
+// every k-loop is straight-line code and the K row loads of an iteration are issued
+// back to back.  Thread i of a workgroup's chunk owns the pair of individuals (2i, 2i+1):
+// one 16-byte load per population row, 4 bits of the 2-bit column.
+template <int KT, bool FIRST, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p) {
+  constexpr int kWaves = BLOCK / 64;
   __shared__ double s_eb[2 * KT];
   __shared__ double s_sb[2 * KT];
   __shared__ double s_red[kWaves][2 * KT];
-  __shared__ double s_fin[kBlock];
+  __shared__ double s_fin[BLOCK];
   __shared__ double s_lam[2 * KT];
   __shared__ double s_diff[2 * KT];
   __shared__ uint32_t s_last;
 
   Ctl *ctl = p.ctl;
   const uint32_t tid = threadIdx.x;
-  const uint32_t K = p.K, J = 2 * K;
+  constexpr uint32_t J = 2 * KT;
   const uint32_t cur = ctl->cursor;
   const uint32_t idx = FIRST ? cur : cur - 1u;
   if (idx >= ctl->sched_len) return;
@@ -134,11 +135,11 @@ __global__ __launch_bounds__(kBlock) void ts_pass(DevParams p) {
   }
   __syncthreads();
 
-  double b0[KT], b1[KT];
+  double b0[KT], b1[KT];  // wave-uniform: kept in SGPRs
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
-    b0[k] = (k < (int)K) ? s_eb[2 * k] : 0.0;
-    b1[k] = (k < (int)K) ? s_eb[2 * k + 1] : 0.0;
+    b0[k] = uniform_f64(s_eb[2 * k]);
+    b1[k] = uniform_f64(s_eb[2 * k + 1]);
   }
   double acc0[KT], acc1[KT];
 #pragma unroll
@@ -146,120 +147,184 @@ __global__ __launch_bounds__(kBlock) void ts_pass(DevParams p) {
 
   const uint8_t *col = p.bed + (size_t)loc * p.colstride;
   const uint8_t *pcol = p.bed + (size_t)prev_loc * p.colstride;
-  const uint32_t begin = blockIdx.x * p.chunk;
-  const uint32_t end = min(begin + p.chunk, p.npairs);
+  const uint32_t chunk = FIRST ? p.chunk_first : p.chunk;
+  const uint32_t begin = blockIdx.x * chunk;
+  const uint32_t end = min(begin + chunk, p.npairs);
+  const size_t np = p.npad;
 
-  for (uint32_t i = begin + tid; i < end; i += kBlock) {
-    double wa[KT], wb[KT];
+  // ---- main sweep -------------------------------------------------------------------
+  auto load_w = [&](uint32_t i, double2 (&wv)[KT], uint32_t &byte) {
 #pragma unroll
-    for (int k = 0; k < KT; ++k)
-      if (k < (int)K) {
-        const double2 v = reinterpret_cast<const double2 *>(p.w + (size_t)k * p.npad)[i];
-        wa[k] = v.x;
-        wb[k] = v.y;
-      }
-    const uint32_t code = ((uint32_t)col[i >> 1] >> (4u * (i & 1u))) & 0xfu;
-
-    if (FIRST && do_gamma) {
-      double sb0[KT], sb1[KT];
-#pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        sb0[k] = (k < (int)K) ? s_sb[2 * k] : 0.0;
-        sb1[k] = (k < (int)K) ? s_sb[2 * k + 1] : 0.0;
-      }
-      double ga[KT], gb[KT];
-#pragma unroll
-      for (int k = 0; k < KT; ++k)
-        if (k < (int)K) {
-          const double2 v = reinterpret_cast<const double2 *>(p.gam + (size_t)k * p.npad)[i];
-          ga[k] = v.x;
-          gb[k] = v.y;
-        }
-      uint2 cn = reinterpret_cast<const uint2 *>(p.cnt)[i];
-      const uint32_t pcode = ((uint32_t)pcol[i >> 1] >> (4u * (i & 1u))) & 0xfu;
-      double mom, dad;
-      bool ok;
-      code_weights(pcode & 3u, mom, dad, ok);
-      if (ok) {
-        gamma_step_one<KT>(ga, wa, sb0, sb1, mom, dad, cn.x, p);
-        gamma_to_w<KT>(ga, wa, K);
-      }
-      code_weights(pcode >> 2, mom, dad, ok);
-      if (ok) {
-        gamma_step_one<KT>(gb, wb, sb0, sb1, mom, dad, cn.y, p);
-        gamma_to_w<KT>(gb, wb, K);
-      }
-#pragma unroll
-      for (int k = 0; k < KT; ++k)
-        if (k < (int)K) {
-          reinterpret_cast<double2 *>(p.gam + (size_t)k * p.npad)[i] = make_double2(ga[k], gb[k]);
-          reinterpret_cast<double2 *>(p.w + (size_t)k * p.npad)[i] = make_double2(wa[k], wb[k]);
-        }
-      reinterpret_cast<uint2 *>(p.cnt)[i] = cn;
-    }
-
+    for (int k = 0; k < KT; ++k) wv[k] = reinterpret_cast<const double2 *>(p.w + (size_t)k * np)[i];
+    byte = reinterpret_cast<const uint32_t *>(col)[i >> 3];  // 8 pairs per dword: lanes share addresses
+  };
+  auto accumulate = [&](uint32_t i, const double (&wa)[KT], const double (&wb)[KT], uint32_t byte) {
+    const uint32_t code = (byte >> (4u * (i & 7u))) & 0xfu;
     double ma, da, mb, db;
     bool oka, okb;
     code_weights(code & 3u, ma, da, oka);
     code_weights(code >> 2, mb, db, okb);
     double s0a = 0.0, s1a = 0.0, s0b = 0.0, s1b = 0.0;
 #pragma unroll
-    for (int k = 0; k < KT; ++k)
-      if (k < (int)K) {
-        s0a = fma(wa[k], b0[k], s0a);
-        s1a = fma(wa[k], b1[k], s1a);
-        s0b = fma(wb[k], b0[k], s0b);
-        s1b = fma(wb[k], b1[k], s1b);
-      }
+    for (int k = 0; k < KT; ++k) {
+      s0a = fma(wa[k], b0[k], s0a);
+      s1a = fma(wa[k], b1[k], s1a);
+      s0b = fma(wb[k], b0[k], s0b);
+      s1b = fma(wb[k], b1[k], s1b);
+    }
     const double ca0 = ma / s0a, ca1 = da / s1a, cb0 = mb / s0b, cb1 = db / s1b;
 #pragma unroll
-    for (int k = 0; k < KT; ++k)
-      if (k < (int)K) {
-        acc0[k] = fma(ca0, wa[k], fma(cb0, wb[k], acc0[k]));
-        acc1[k] = fma(ca1, wa[k], fma(cb1, wb[k], acc1[k]));
-      }
-  }
+    for (int k = 0; k < KT; ++k) {
+      acc0[k] = fma(ca0, wa[k], fma(cb0, wb[k], acc0[k]));
+      acc1[k] = fma(ca1, wa[k], fma(cb1, wb[k], acc1[k]));
+    }
+  };
 
-  // workgroup reduction, fixed order: lanes (xor tree) -> waves (0..3)
-  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  if constexpr (!FIRST) {
+    // two-stage software pipeline: the next iteration's K row loads are in flight while
+    // the current one is reduced
+    auto consume = [&](uint32_t i, const double2 (&wv)[KT], uint32_t byte) {
+      double wa[KT], wb[KT];
 #pragma unroll
-  for (int k = 0; k < KT; ++k)
-    if (k < (int)K) {
-      const double r0 = wave_sum(acc0[k]);
-      const double r1 = wave_sum(acc1[k]);
-      if (lane == 0) {
-        s_red[wave][2 * k] = r0;
-        s_red[wave][2 * k + 1] = r1;
+      for (int k = 0; k < KT; ++k) {
+        wa[k] = wv[k].x;
+        wb[k] = wv[k].y;
+      }
+      accumulate(i, wa, wb, byte);
+    };
+    // (prefetch addresses are clamped, not predicated, so the load/wait counts are static)
+    double2 bufA[KT], bufB[KT];
+    uint32_t byteA = 0, byteB = 0;
+    uint32_t i = begin + tid;
+    if (i < end) {
+      load_w(i, bufA, byteA);
+      while (true) {
+        const uint32_t i1 = i + BLOCK;
+        load_w(i1 < end ? i1 : i, bufB, byteB);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
+        consume(i, bufA, byteA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i1 >= end) break;
+        const uint32_t i2 = i1 + BLOCK;
+        load_w(i2 < end ? i2 : i1, bufA, byteA);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(i1, bufB, byteB);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i2 >= end) break;
+        i = i2;
       }
     }
+  } else {
+    for (uint32_t i = begin + tid; i < end; i += BLOCK) {
+      double2 wv[KT];
+      uint32_t byte;
+      load_w(i, wv, byte);
+      double wa[KT], wb[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        wa[k] = wv[k].x;
+        wb[k] = wv[k].y;
+      }
+      if (do_gamma) {
+        double ga[KT], gb[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          const double2 v = reinterpret_cast<const double2 *>(p.gam + (size_t)k * np)[i];
+          ga[k] = v.x;
+          gb[k] = v.y;
+        }
+        uint2 cn = reinterpret_cast<const uint2 *>(p.cnt)[i];
+        const uint32_t pcode = ((uint32_t)pcol[i >> 1] >> (4u * (i & 1u))) & 0xfu;
+        double sb0[KT], sb1[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          sb0[k] = s_sb[2 * k];
+          sb1[k] = s_sb[2 * k + 1];
+        }
+        double mom, dad;
+        bool ok;
+        code_weights(pcode & 3u, mom, dad, ok);
+        if (ok) {
+          gamma_step_one<KT>(ga, wa, sb0, sb1, mom, dad, cn.x, p);
+          gamma_to_w<KT>(ga, wa);
+        }
+        code_weights(pcode >> 2, mom, dad, ok);
+        if (ok) {
+          gamma_step_one<KT>(gb, wb, sb0, sb1, mom, dad, cn.y, p);
+          gamma_to_w<KT>(gb, wb);
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          reinterpret_cast<double2 *>(p.gam + (size_t)k * np)[i] = make_double2(ga[k], gb[k]);
+          reinterpret_cast<double2 *>(p.w + (size_t)k * np)[i] = make_double2(wa[k], wb[k]);
+        }
+        reinterpret_cast<uint2 *>(p.cnt)[i] = cn;
+      }
+      accumulate(i, wa, wb, byte);
+    }
+  }
+
+  // workgroup reduction, fixed order: lanes (halving butterfly) -> waves (0..kWaves-1)
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  {
+    using Fold = WaveFold<2 * KT>;
+    double v[Fold::P];
+#pragma unroll
+    for (int q = 0; q < Fold::P; ++q) v[q] = 0.0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      v[2 * k] = acc0[k];
+      v[2 * k + 1] = acc1[k];
+    }
+    const double tot = Fold::fold(v, lane);
+    const int slot = Fold::slot(lane);
+    constexpr uint32_t kRep = 64 / Fold::P;  // lanes sharing one slot
+    if ((lane & (kRep - 1u)) == 0u && slot < (int)J) s_red[wave][slot] = tot;
+  }
   __syncthreads();
   if (tid < J) {
     double v = s_red[0][tid];
 #pragma unroll
     for (int wv = 1; wv < kWaves; ++wv) v += s_red[wv][tid];
-    st_agent(p.partials + (size_t)blockIdx.x * J + tid, v);
+    if (p.tail == 2u)
+      p.partials[(size_t)blockIdx.x * J + tid] = v;
+    else
+      st_agent(p.partials + (size_t)blockIdx.x * J + tid, v);
   }
-  // hand-off to the last-arriving workgroup: drain stores, release, ticket, acquire
+  if (p.tail == 2u) return;  // ts_finish (next kernel) adds the partial rows up
+  // hand-off to the last-arriving workgroup.  The partial rows are written through to
+  // the coherence point (agent-scope sc1 stores) and read back with agent-scope loads, so
+  // no L2 write-back / L1 invalidate is needed: every storing wave drains its stores,
+  // the workgroup barrier orders them before lane 0's arrival on the ticket, and the
+  // last arriver reads the rows only after its ticket value has returned.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t t = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t last = (t == gridDim.x - 1u) ? 1u : 0u;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    s_last = last;
+    s_last = (t == gridDim.x - 1u) ? 1u : 0u;
   }
   __syncthreads();
+  asm volatile("" ::: "memory");
   if (!s_last) return;
 
   // grid reduction by the last workgroup, fixed order: thread (r, j) sums
-  // partials[g][j] for g = r, r+R, ...; then r = 0..R-1.
-  const uint32_t R = kBlock / J;  // J <= 64 -> R >= 4
+  // partials[g][j] for g = r, r+R, ... (loads batched 8 deep); then r = 0..R-1.
+  constexpr uint32_t R = BLOCK / J;  // J <= 64 -> R >= 4
   const uint32_t j = tid % J, r = tid / J;
+  const uint32_t G = gridDim.x;
   double v = 0.0;
-  if (r < R)
-    for (uint32_t g = r; g < gridDim.x; g += R) v += ld_agent(p.partials + (size_t)g * J + j);
+  if (r < R) {
+    for (uint32_t g0 = r; g0 < G; g0 += 8u * R) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t g = g0 + (uint32_t)u * R;
+        t[u] = ld_agent(p.partials + (size_t)min(g, G - 1u) * J + j);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += (g0 + (uint32_t)u * R < G) ? t[u] : 0.0;
+    }
+  }
   s_fin[tid] = v;
   __syncthreads();
   double lt = 0.0;
@@ -268,11 +333,53 @@ __global__ __launch_bounds__(kBlock) void ts_pass(DevParams p) {
     lt *= s_eb[tid];  // the b[k,t] factored out of the accumulation
   }
   if (tid == 0) ctl->ticket = 0u;
-  if (p.multi) {
+  if (p.tail == 1u) {
     if (tid < J) ctl->lt[tid] = lt;
     return;
   }
   epilogue_block<FIRST>(p, ctl, cur, loc, hol, lt, (tid < J) ? s_eb[tid] : 0.0, s_lam, s_diff);
+}
+
+// tail == 2: the partial rows of the preceding ts_pass launch (grid G) are added up in
+// the same fixed order by one workgroup after the kernel boundary; then either the
+// epilogue (single GPU) or ctl->lt for the all-reduce (to_lt).
+template <bool FIRST>
+__global__ __launch_bounds__(256) void ts_finish(DevParams p, uint32_t G, uint32_t to_lt) {
+  __shared__ double s_fin[256];
+  __shared__ double s_lam[2 * TSAMD_MAX_K];
+  __shared__ double s_diff[2 * TSAMD_MAX_K];
+  Ctl *ctl = p.ctl;
+  const uint32_t tid = threadIdx.x, J = 2 * p.K;
+  const uint32_t cur = ctl->cursor;
+  const uint32_t idx = FIRST ? cur : cur - 1u;
+  if (idx >= ctl->sched_len) return;
+  if (!FIRST && ctl->done) return;
+  const uint32_t ent = p.sched[idx];
+  const uint32_t loc = ent & 0x7fffffffu, hol = ent >> 31;
+  const uint32_t R = 256u / J;
+  const uint32_t j = tid % J, r = tid / J;
+  double v = 0.0;
+  if (r < R)
+    for (uint32_t g0 = r; g0 < G; g0 += 8u * R) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = p.partials[(size_t)min(g0 + (uint32_t)u * R, G - 1u) * J + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += (g0 + (uint32_t)u * R < G) ? t[u] : 0.0;
+    }
+  s_fin[tid] = v;
+  __syncthreads();
+  const double ebj = (tid < J) ? p.eb[(size_t)loc * J + tid] : 0.0;
+  double lt = 0.0;
+  if (tid < J) {
+    for (uint32_t rr = 0; rr < R; ++rr) lt += s_fin[rr * J + tid];
+    lt *= ebj;
+  }
+  if (to_lt) {
+    if (tid < J) ctl->lt[tid] = lt;
+    return;
+  }
+  epilogue_block<FIRST>(p, ctl, cur, loc, hol, lt, ebj, s_lam, s_diff);
 }
 
 // multi-GPU: epilogue after the RCCL all-reduce of ctl->lt into ctl->lt_sum
@@ -299,158 +406,21 @@ __global__ __launch_bounds__(kBlock) void ts_refresh_w(DevParams p) {
   if (i >= p.npairs) return;
   double ga[KT], gb[KT], wa[KT], wb[KT];
 #pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    const double2 v = reinterpret_cast<const double2 *>(p.gam + (size_t)k * p.npad)[i];
+    ga[k] = v.x;
+    gb[k] = v.y;
+  }
+  gamma_to_w<KT>(ga, wa);
+  gamma_to_w<KT>(gb, wb);
+#pragma unroll
   for (int k = 0; k < KT; ++k)
-    if (k < (int)p.K) {
-      const double2 v = reinterpret_cast<const double2 *>(p.gam + (size_t)k * p.npad)[i];
-      ga[k] = v.x;
-      gb[k] = v.y;
-    }
-  gamma_to_w<KT>(ga, wa, p.K);
-  gamma_to_w<KT>(gb, wb, p.K);
-#pragma unroll
-  for (int k = 0; k < KT; ++k)
-    if (k < (int)p.K) reinterpret_cast<double2 *>(p.w + (size_t)k * p.npad)[i] = make_double2(wa[k], wb[k]);
+    reinterpret_cast<double2 *>(p.w + (size_t)k * p.npad)[i] = make_double2(wa[k], wb[k]);
 }
 
-// mode 0: gamma, 1: theta = gamma / sum, 2: Elogtheta = psi(gamma) - psi(sum)
-// (estimate_all_theta src/snpsamplinge.cc:595-609, set_dir_exp src/lib.hh:19-35);
-// out is row-major [n_out][K]; rows = list of local individual ids or NULL for 0..n_out-1.
-__global__ void ts_export_indiv(const double *gam, uint32_t npad, uint32_t K, uint32_t n_out,
-                                const uint32_t *rows, int mode, double *out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_out) return;
-  const uint32_t n = rows ? rows[i] : i;
-  double s = 0.0;
-  for (uint32_t k = 0; k < K; ++k) s += gam[(size_t)k * npad + n];
-  const double ps = (mode == 2) ? digamma(s) : 0.0;
-  for (uint32_t k = 0; k < K; ++k) {
-    const double g = gam[(size_t)k * npad + n];
-    out[(size_t)i * K + k] = (mode == 0) ? g : (mode == 1) ? g / s : digamma(g) - ps;
-  }
-}
-
-// mode 0: Ebeta[loc][k] = l0/(l0+l1); mode 1: Elogbeta[loc][k][t]; mode 2: exp(Elogbeta) into eb
-// (estimate_beta, src/snpsamplinge.cc:279-296)
-__global__ void ts_export_loc(const double *lam, uint32_t K, uint32_t first_loc, uint32_t n_locs, int mode,
-                              double *out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_locs * K) return;
-  const uint32_t loc = first_loc + i / K, k = i % K;
-  const double l0 = lam[((size_t)loc * K + k) * 2], l1 = lam[((size_t)loc * K + k) * 2 + 1];
-  double s = 0.0;
-  s += l0;
-  s += l1;
-  if (mode == 0) {
-    out[i] = l0 / s;
-  } else {
-    const double ps = digamma(s);
-    const double e0 = digamma(l0) - ps, e1 = digamma(l1) - ps;
-    double *o = (mode == 1) ? out + (size_t)i * 2 : out + ((size_t)loc * K + k) * 2;
-    o[0] = (mode == 1) ? e0 : exp(e0);
-    o[1] = (mode == 1) ? e1 : exp(e1);
-  }
-}
-
-// fold validation entries into the column as "missing" (01) and return the true codes
-__global__ void ts_heldout_fold(uint8_t *col, const uint32_t *local_ids, uint32_t count, uint8_t *orig) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const uint32_t n = local_ids[i];
-  uint32_t *word = reinterpret_cast<uint32_t *>(col) + (n >> 4);
-  const uint32_t sh = 2u * (n & 15u);
-  const uint32_t old = atomicOr(word, 1u << sh);
-  atomicAnd(word, ~(2u << sh));
-  orig[i] = (uint8_t)((old >> sh) & 3u);
-}
-
-// per-entry held-out log-likelihood term (snp_likelihood, src/snpsamplinge.hh:336-360)
-__global__ void ts_heldout_ll(const double *gam, uint32_t npad, uint32_t K, const double *lam_loc,
-                              const uint32_t *local_ids, const uint8_t *ytrue, uint32_t count, double *out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const uint32_t n = local_ids[i];
-  double s = 0.0;
-  for (uint32_t k = 0; k < K; ++k) s += gam[(size_t)k * npad + n];
-  double q = 0.0;
-  for (uint32_t k = 0; k < K; ++k) {
-    const double l0 = lam_loc[2 * k], l1 = lam_loc[2 * k + 1];
-    double ls = 0.0;
-    ls += l0;
-    ls += l1;
-    q += (l0 / ls) * (gam[(size_t)k * npad + n] / s);
-  }
-  const int x = ytrue[i];
-  const double v = (x == 1) ? 2.0 : 1.0;  // 2!/(x!(2-x)!)
-  double sum = v * pow(q, (double)x) * pow(1.0 - q, (double)(2 - x));
-  if (sum < 1e-30) sum = 1e-30;
-  out[i] = log(sum);
-}
-
-// ---------------------------------------------------------------------------
-// Synthetic Pritchard-Stephens-Donnelly genotypes: one thread makes one
-// column byte (4 individuals) for CT consecutive columns.
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-  z += 0x9e3779b97f4a7c15ull;
-  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-  return z ^ (z >> 31);
-}
-
-constexpr int kSynthCols = 8;
-
-__global__ __launch_bounds__(kBlock) void ts_synth(uint8_t *bed, uint64_t colstride, const double *theta_kmajor,
-                                                  uint32_t npad, uint32_t n_local, uint32_t n_begin, uint32_t K,
-                                                  const double *beta, uint32_t first_loc, uint32_t n_locs,
-                                                  uint64_t seed, double missing_rate) {
-  __shared__ double s_beta[kSynthCols * TSAMD_MAX_K];
-  const uint32_t q = blockIdx.x * kBlock + threadIdx.x;  // quad of individuals
-  const uint32_t c0 = blockIdx.y * kSynthCols;
-  const uint32_t nc = min((uint32_t)kSynthCols, n_locs - c0);
-  for (uint32_t t = threadIdx.x; t < nc * K; t += kBlock) s_beta[t] = beta[(size_t)c0 * K + t];
-  __syncthreads();
-  if (q >= npad / 4) return;
-  double pr[kSynthCols][4];
-#pragma unroll
-  for (int c = 0; c < kSynthCols; ++c)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) pr[c][u] = 0.0;
-  for (uint32_t k = 0; k < K; ++k) {
-    const double2 t01 = reinterpret_cast<const double2 *>(theta_kmajor + (size_t)k * npad)[2 * q];
-    const double2 t23 = reinterpret_cast<const double2 *>(theta_kmajor + (size_t)k * npad)[2 * q + 1];
-#pragma unroll
-    for (int c = 0; c < kSynthCols; ++c) {
-      const double b = (c < (int)nc) ? s_beta[c * K + k] : 0.0;
-      pr[c][0] = fma(t01.x, b, pr[c][0]);
-      pr[c][1] = fma(t01.y, b, pr[c][1]);
-      pr[c][2] = fma(t23.x, b, pr[c][2]);
-      pr[c][3] = fma(t23.y, b, pr[c][3]);
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < kSynthCols; ++c) {
-    if (c >= (int)nc) break;
-    const uint32_t loc = first_loc + c0 + c;
-    uint32_t byte = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t nl = 4 * q + u;
-      uint32_t code = 1u;  // padding individuals are missing
-      if (nl < n_local) {
-        const uint64_t key = ((uint64_t)loc << 32) | (uint64_t)(n_begin + nl);
-        const uint64_t h = mix64(mix64(seed) ^ key);
-        const double u1 = (double)(uint32_t)(h >> 32) * (1.0 / 4294967296.0);
-        const double u2 = (double)(uint32_t)h * (1.0 / 4294967296.0);
-        const uint32_t y = (u1 < pr[c][u] ? 1u : 0u) + (u2 < pr[c][u] ? 1u : 0u);
-        code = (y == 0u) ? 0u : (y == 1u) ? 2u : 3u;
-        if (missing_rate > 0.0) {
-          const uint64_t h2 = mix64(h);
-          if ((double)(uint32_t)(h2 >> 32) * (1.0 / 4294967296.0) < missing_rate) code = 1u;
-        }
-      }
-      byte |= code << (2 * u);
-    }
-    bed[(size_t)loc * colstride + q] = (uint8_t)byte;
-  }
-}
+// Host-side launcher of the K-specialised kernels; one translation unit per K
+// (tsamd_inst.hip compiled with -DTSAMD_K=<k>) defines tsamd::launch_k<k>.
+enum LaunchWhich { kLaunchPass = 0, kLaunchFirst = 1, kLaunchRefresh = 2 };
+using LaunchFn = void (*)(int which, uint32_t grid, uint32_t block, hipStream_t stream, const DevParams &p);
 
 }  // namespace tsamd

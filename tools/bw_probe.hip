@@ -1,0 +1,62 @@
+// Read-bandwidth probe for MI355X: streaming double2 reads with a trivial reduction.
+//   variant 0: one contiguous stream per workgroup chunk
+//   variant 1: 8 row streams (k-major [8][n]) like the engine's weight array
+//   variant 2: tile-interleaved [(n/64)][8][64] (a wave reads 8 KB contiguous)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+template <int VAR>
+__global__ __launch_bounds__(256) void rd(const double2 *__restrict__ a, size_t npairs, uint32_t chunk, double *out) {
+  const uint32_t begin = blockIdx.x * chunk;
+  const uint32_t end = min((size_t)begin + chunk, npairs);
+  double acc = 0.0;
+  for (uint32_t i = begin + threadIdx.x; i < end; i += 256) {
+    double2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      size_t idx;
+      if (VAR == 0) idx = (size_t)begin * 8 + (size_t)(i - begin) + (size_t)k * (end - begin);  // 8 sub-streams inside the chunk
+      else if (VAR == 1) idx = (size_t)k * npairs + i;
+      else idx = (((size_t)(i >> 6) * 8 + k) << 6) | (i & 63);
+      v[k] = a[idx];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += v[k].x + v[k].y;
+  }
+  if (acc == 123.456) out[0] = acc;
+}
+
+int main() {
+  const size_t sizes_mb[] = {64, 256, 2048};
+  for (size_t mb : sizes_mb) {
+    const size_t bytes = mb << 20;
+    const size_t npairs = bytes / 16 / 8;  // pairs per row; 8 rows
+    double2 *a; double *out;
+    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&out, 8));
+    CK(hipMemset(a, 0, bytes));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int var = 0; var < 3; ++var)
+      for (uint32_t grid : {256u, 512u, 1024u, 2048u, 4096u}) {
+        uint32_t chunk = (npairs + grid - 1) / grid; chunk = (chunk + 255) / 256 * 256;
+        const uint32_t g = (npairs + chunk - 1) / chunk;
+        auto launch = [&]() {
+          if (var == 0) hipLaunchKernelGGL(rd<0>, dim3(g), dim3(256), 0, 0, a, npairs, chunk, out);
+          else if (var == 1) hipLaunchKernelGGL(rd<1>, dim3(g), dim3(256), 0, 0, a, npairs, chunk, out);
+          else hipLaunchKernelGGL(rd<2>, dim3(g), dim3(256), 0, 0, a, npairs, chunk, out);
+        };
+        for (int w = 0; w < 3; ++w) launch();
+        CK(hipEventRecord(e0, 0));
+        const int reps = 20;
+        for (int r = 0; r < reps; ++r) launch();
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("size %4zu MB var %d grid %4u: %.2f us/launch  %.0f GB/s\n", mb, var, g, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e9);
+      }
+    CK(hipFree(a)); CK(hipFree(out));
+  }
+  return 0;
+}
