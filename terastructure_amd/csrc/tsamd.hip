@@ -83,7 +83,7 @@ struct tsamd_ctx {
   int dev = 0;
   hipStream_t stream = nullptr;
   uint32_t n_begin = 0, n_local = 0, npad = 0;
-  uint32_t grid = 0, block = 256, grid_first = 0;  // plain-pass and first-pass launch geometry
+  uint32_t grid = 0, block = 256, grid_first = 0, first_vec = 1;  // plain-pass and first-pass launch geometry
   DevParams p{};
   uint32_t *d_sched = nullptr;
   uint32_t sched_cap = 0;
@@ -152,7 +152,7 @@ __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
 
 void launch_pass(tsamd_ctx *c, bool first) {
   if (first)
-    kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, 256, c->stream, c->p);
+    kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p);
   else
     kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p);
 }
@@ -409,24 +409,24 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
     const char *s = getenv(name);
     return (s && *s) ? (uint32_t)std::max(0, atoi(s)) : dflt;
   };
-  uint32_t block = (cfg->k <= 8) ? 1024u : (cfg->k <= 16) ? 512u : 256u;
-  while (block > 256u && p.npairs < 64u * block) block /= 2;  // small shards: fewer, smaller groups
-  block = env_u32("TSAMD_BLOCK", block);
+  uint32_t block = env_u32("TSAMD_BLOCK", 256);
   if (block != 256u && block != 512u && block != 1024u) block = 256u;
-  auto geometry = [&](uint32_t blk, uint32_t target, uint32_t &chunk, uint32_t &grid) {
+  if (block == 1024u && cfg->k > 8) block = 512u;  // register budget of the pipelined loop
+  auto geometry = [&](uint32_t nitems, uint32_t blk, uint32_t target, uint32_t &chunk, uint32_t &grid) {
     target = std::min<uint32_t>(std::max<uint32_t>(target, 1u), kMaxGrid);
-    chunk = (p.npairs + target - 1) / target;
+    chunk = (nitems + target - 1) / target;
     chunk = (chunk + blk - 1) / blk * blk;
-    grid = (p.npairs + chunk - 1) / chunk;
+    grid = (nitems + chunk - 1) / chunk;
   };
   c->block = block;
+  c->first_vec = env_u32("TSAMD_FIRST_VEC", 1) == 2 ? 2 : 1;
+  geometry(p.npairs, block, env_u32("TSAMD_GRID", 256), p.chunk, c->grid);
+  geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", 512), p.chunk_first, c->grid_first);
   {
     const uint32_t dflt = (cfg->flags & TSAMD_FLAG_FINISH_KERNEL) ? 2u : 0u;
     const uint32_t mode = env_u32("TSAMD_TAIL", dflt);
     p.tail = (mode == 2u) ? 2u : (c->split ? 1u : 0u);
   }
-  geometry(block, env_u32("TSAMD_GRID", 256), p.chunk, c->grid);
-  geometry(256, env_u32("TSAMD_GRID_FIRST", 512), p.chunk_first, c->grid_first);
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
   CREATE_TRY(hipMalloc((void **)&p.w, K * np * sizeof(double)));

@@ -51,8 +51,8 @@ struct DevParams {
   const uint32_t *sched; // entries: loc | hol_mode << 31
   uint32_t npad;       // padded individuals (multiple of 512)
   uint32_t npairs;     // npad / 2
-  uint32_t chunk;      // pairs per workgroup of the plain pass kernel (multiple of its block size)
-  uint32_t chunk_first; // same for the first-pass (gamma-fused) kernel
+  uint32_t chunk;      // items (pairs of individuals) per workgroup of the plain pass kernel
+  uint32_t chunk_first; // items (individuals, or pairs with TSAMD_FIRST_VEC=2) per workgroup of the first pass
   uint32_t K;
   uint32_t max_inner;
   uint32_t tail;       // how a pass ends: 0 = ticket, last workgroup reduces + runs the epilogue;

@@ -17,14 +17,17 @@ void TSAMD_CAT(launch_k, TSAMD_K)(int which, uint32_t grid, uint32_t block, hipS
   switch (which) {
     case kLaunchPass:
       if (block == 1024)
-        hipLaunchKernelGGL((ts_pass<K, false, 1024>), dim3(grid), dim3(1024), 0, stream, p);
+        hipLaunchKernelGGL((ts_pass<K, false, 1024, 2>), dim3(grid), dim3(1024), 0, stream, p);
       else if (block == 512)
-        hipLaunchKernelGGL((ts_pass<K, false, 512>), dim3(grid), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((ts_pass<K, false, 512, 2>), dim3(grid), dim3(512), 0, stream, p);
       else
-        hipLaunchKernelGGL((ts_pass<K, false, 256>), dim3(grid), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((ts_pass<K, false, 256, 2>), dim3(grid), dim3(256), 0, stream, p);
       break;
     case kLaunchFirst:
-      hipLaunchKernelGGL((ts_pass<K, true, 256>), dim3(grid), dim3(256), 0, stream, p);
+      if (block == 1)  // TSAMD_FIRST_VEC=2: two individuals per thread
+        hipLaunchKernelGGL((ts_pass<K, true, 256, 2>), dim3(grid), dim3(256), 0, stream, p);
+      else
+        hipLaunchKernelGGL((ts_pass<K, true, 256, 1>), dim3(grid), dim3(256), 0, stream, p);
       break;
     default:
       hipLaunchKernelGGL((ts_refresh_w<K>), dim3((p.npairs + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, p);

@@ -102,13 +102,41 @@ __device__ __forceinline__ void gamma_step_one(double (&g)[KT], const double (&w
   }
 }
 
+// VEC individuals per thread: 1 (8-byte row loads) or 2 (16-byte row loads).
+template <int VEC>
+struct Lanes;
+template <>
+struct Lanes<1> {
+  using T = double;
+  using C = uint32_t;
+  static __device__ __forceinline__ void unpack(T v, double (&o)[1]) { o[0] = v; }
+  static __device__ __forceinline__ T pack(const double (&o)[1]) { return o[0]; }
+  static __device__ __forceinline__ void unpack_c(C v, uint32_t (&o)[1]) { o[0] = v; }
+  static __device__ __forceinline__ C pack_c(const uint32_t (&o)[1]) { return o[0]; }
+};
+template <>
+struct Lanes<2> {
+  using T = double2;
+  using C = uint2;
+  static __device__ __forceinline__ void unpack(T v, double (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+  static __device__ __forceinline__ T pack(const double (&o)[2]) { return make_double2(o[0], o[1]); }
+  static __device__ __forceinline__ void unpack_c(C v, uint32_t (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+  static __device__ __forceinline__ C pack_c(const uint32_t (&o)[2]) { return make_uint2(o[0], o[1]); }
+};
+
 // One inner pass for the current SNP.  KT == K exactly (one instantiation per K), so
 // every k-loop is straight-line code and the K row loads of an iteration are issued
-// back to back.  Thread i of a workgroup's chunk owns the pair of individuals (2i, 2i+1):
-// one 16-byte load per population row, 4 bits of the 2-bit column.
-template <int KT, bool FIRST, int BLOCK>
+// back to back.  Item i of a workgroup's chunk is VEC consecutive individuals: one
+// 8*VEC-byte load per population row and 2*VEC bits of the 2-bit column.  The plain
+// pass uses VEC = 2; the first pass, which also carries the gamma step, uses VEC = 1 to
+// halve its register footprint.
+template <int KT, bool FIRST, int BLOCK, int VEC>
 __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p) {
   constexpr int kWaves = BLOCK / 64;
+  using LN = Lanes<VEC>;
+  using WT = typename LN::T;
+  constexpr uint32_t kItemsPerWord = 16u / VEC;  // items per 32-bit word of the column
+  constexpr uint32_t kCodeBits = 2u * VEC;
   __shared__ double s_eb[2 * KT];
   __shared__ double s_sb[2 * KT];
   __shared__ double s_red[kWaves][2 * KT];
@@ -145,122 +173,134 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p) {
 #pragma unroll
   for (int k = 0; k < KT; ++k) acc0[k] = acc1[k] = 0.0;
 
-  const uint8_t *col = p.bed + (size_t)loc * p.colstride;
-  const uint8_t *pcol = p.bed + (size_t)prev_loc * p.colstride;
+  const uint32_t *col = reinterpret_cast<const uint32_t *>(p.bed + (size_t)loc * p.colstride);
+  const uint32_t *pcol = reinterpret_cast<const uint32_t *>(p.bed + (size_t)prev_loc * p.colstride);
+  const uint32_t nitems = p.npad / VEC;
   const uint32_t chunk = FIRST ? p.chunk_first : p.chunk;
   const uint32_t begin = blockIdx.x * chunk;
-  const uint32_t end = min(begin + chunk, p.npairs);
+  const uint32_t end = min(begin + chunk, nitems);
   const size_t np = p.npad;
 
   // ---- main sweep -------------------------------------------------------------------
-  auto load_w = [&](uint32_t i, double2 (&wv)[KT], uint32_t &byte) {
+  auto load_w = [&](uint32_t i, WT (&wv)[KT], uint32_t &word) {
 #pragma unroll
-    for (int k = 0; k < KT; ++k) wv[k] = reinterpret_cast<const double2 *>(p.w + (size_t)k * np)[i];
-    byte = reinterpret_cast<const uint32_t *>(col)[i >> 3];  // 8 pairs per dword: lanes share addresses
+    for (int k = 0; k < KT; ++k) wv[k] = reinterpret_cast<const WT *>(p.w + (size_t)k * np)[i];
+    word = col[i / kItemsPerWord];  // lanes share addresses
   };
-  auto accumulate = [&](uint32_t i, const double (&wa)[KT], const double (&wb)[KT], uint32_t byte) {
-    const uint32_t code = (byte >> (4u * (i & 7u))) & 0xfu;
-    double ma, da, mb, db;
-    bool oka, okb;
-    code_weights(code & 3u, ma, da, oka);
-    code_weights(code >> 2, mb, db, okb);
-    double s0a = 0.0, s1a = 0.0, s0b = 0.0, s1b = 0.0;
+  auto accumulate = [&](uint32_t i, const double (&w)[VEC][KT], uint32_t word) {
+    const uint32_t code = word >> (kCodeBits * (i % kItemsPerWord));
+    double c0[VEC], c1[VEC];
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      s0a = fma(wa[k], b0[k], s0a);
-      s1a = fma(wa[k], b1[k], s1a);
-      s0b = fma(wb[k], b0[k], s0b);
-      s1b = fma(wb[k], b1[k], s1b);
+    for (int v = 0; v < VEC; ++v) {
+      double mom, dad;
+      bool ok;
+      code_weights((code >> (2 * v)) & 3u, mom, dad, ok);
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        s0 = fma(w[v][k], b0[k], s0);
+        s1 = fma(w[v][k], b1[k], s1);
+      }
+      c0[v] = mom / s0;
+      c1[v] = dad / s1;
     }
-    const double ca0 = ma / s0a, ca1 = da / s1a, cb0 = mb / s0b, cb1 = db / s1b;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+      for (int v = VEC - 1; v >= 0; --v) {
+        acc0[k] = fma(c0[v], w[v][k], acc0[k]);
+        acc1[k] = fma(c1[v], w[v][k], acc1[k]);
+      }
+  };
+  auto unpack_rows = [&](const WT (&wv)[KT], double (&w)[VEC][KT]) {
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-      acc0[k] = fma(ca0, wa[k], fma(cb0, wb[k], acc0[k]));
-      acc1[k] = fma(ca1, wa[k], fma(cb1, wb[k], acc1[k]));
+      double t[VEC];
+      LN::unpack(wv[k], t);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) w[v][k] = t[v];
     }
   };
 
   if constexpr (!FIRST) {
     // two-stage software pipeline: the next iteration's K row loads are in flight while
     // the current one is reduced
-    auto consume = [&](uint32_t i, const double2 (&wv)[KT], uint32_t byte) {
-      double wa[KT], wb[KT];
-#pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        wa[k] = wv[k].x;
-        wb[k] = wv[k].y;
-      }
-      accumulate(i, wa, wb, byte);
+    auto consume = [&](uint32_t i, const WT (&wv)[KT], uint32_t word) {
+      double w[VEC][KT];
+      unpack_rows(wv, w);
+      accumulate(i, w, word);
     };
     // (prefetch addresses are clamped, not predicated, so the load/wait counts are static)
-    double2 bufA[KT], bufB[KT];
-    uint32_t byteA = 0, byteB = 0;
+    WT bufA[KT], bufB[KT];
+    uint32_t wordA = 0, wordB = 0;
     uint32_t i = begin + tid;
     if (i < end) {
-      load_w(i, bufA, byteA);
+      load_w(i, bufA, wordA);
       while (true) {
         const uint32_t i1 = i + BLOCK;
-        load_w(i1 < end ? i1 : i, bufB, byteB);
+        load_w(i1 < end ? i1 : i, bufB, wordB);
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
-        consume(i, bufA, byteA);
+        consume(i, bufA, wordA);
         __builtin_amdgcn_sched_barrier(0);
         if (i1 >= end) break;
         const uint32_t i2 = i1 + BLOCK;
-        load_w(i2 < end ? i2 : i1, bufA, byteA);
+        load_w(i2 < end ? i2 : i1, bufA, wordA);
         __builtin_amdgcn_sched_barrier(0);
-        consume(i1, bufB, byteB);
+        consume(i1, bufB, wordB);
         __builtin_amdgcn_sched_barrier(0);
         if (i2 >= end) break;
         i = i2;
       }
     }
   } else {
+    double sb0[KT], sb1[KT];  // exp(Elogbeta) of the previous SNP's last pass (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      sb0[k] = do_gamma ? uniform_f64(s_sb[2 * k]) : 0.0;
+      sb1[k] = do_gamma ? uniform_f64(s_sb[2 * k + 1]) : 0.0;
+    }
     for (uint32_t i = begin + tid; i < end; i += BLOCK) {
-      double2 wv[KT];
-      uint32_t byte;
-      load_w(i, wv, byte);
-      double wa[KT], wb[KT];
-#pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        wa[k] = wv[k].x;
-        wb[k] = wv[k].y;
-      }
+      WT wv[KT];
+      uint32_t word;
+      load_w(i, wv, word);
+      double w[VEC][KT];
       if (do_gamma) {
-        double ga[KT], gb[KT];
+        WT gv[KT];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
-          const double2 v = reinterpret_cast<const double2 *>(p.gam + (size_t)k * np)[i];
-          ga[k] = v.x;
-          gb[k] = v.y;
-        }
-        uint2 cn = reinterpret_cast<const uint2 *>(p.cnt)[i];
-        const uint32_t pcode = ((uint32_t)pcol[i >> 1] >> (4u * (i & 1u))) & 0xfu;
-        double sb0[KT], sb1[KT];
+        for (int k = 0; k < KT; ++k) gv[k] = reinterpret_cast<const WT *>(p.gam + (size_t)k * np)[i];
+        typename LN::C cv = reinterpret_cast<const typename LN::C *>(p.cnt)[i];
+        const uint32_t pcode = pcol[i / kItemsPerWord] >> (kCodeBits * (i % kItemsPerWord));
+        unpack_rows(wv, w);
+        double g[VEC][KT];
+        unpack_rows(gv, g);
+        uint32_t cn[VEC];
+        LN::unpack_c(cv, cn);
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
-          sb0[k] = s_sb[2 * k];
-          sb1[k] = s_sb[2 * k + 1];
-        }
-        double mom, dad;
-        bool ok;
-        code_weights(pcode & 3u, mom, dad, ok);
-        if (ok) {
-          gamma_step_one<KT>(ga, wa, sb0, sb1, mom, dad, cn.x, p);
-          gamma_to_w<KT>(ga, wa);
-        }
-        code_weights(pcode >> 2, mom, dad, ok);
-        if (ok) {
-          gamma_step_one<KT>(gb, wb, sb0, sb1, mom, dad, cn.y, p);
-          gamma_to_w<KT>(gb, wb);
+        for (int v = 0; v < VEC; ++v) {
+          double mom, dad;
+          bool ok;
+          code_weights((pcode >> (2 * v)) & 3u, mom, dad, ok);
+          if (ok) {
+            gamma_step_one<KT>(g[v], w[v], sb0, sb1, mom, dad, cn[v], p);
+            gamma_to_w<KT>(g[v], w[v]);
+          }
         }
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-          reinterpret_cast<double2 *>(p.gam + (size_t)k * np)[i] = make_double2(ga[k], gb[k]);
-          reinterpret_cast<double2 *>(p.w + (size_t)k * np)[i] = make_double2(wa[k], wb[k]);
+          double tg[VEC], tw[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            tg[v] = g[v][k];
+            tw[v] = w[v][k];
+          }
+          reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = LN::pack(tg);
+          reinterpret_cast<WT *>(p.w + (size_t)k * np)[i] = LN::pack(tw);
         }
-        reinterpret_cast<uint2 *>(p.cnt)[i] = cn;
+        reinterpret_cast<typename LN::C *>(p.cnt)[i] = LN::pack_c(cn);
+      } else {
+        unpack_rows(wv, w);
       }
-      accumulate(i, wa, wb, byte);
+      accumulate(i, w, word);
     }
   }
 
