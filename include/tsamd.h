@@ -61,8 +61,7 @@ typedef struct tsamd_config {
   uint32_t flags;       /* TSAMD_FLAG_* */
 } tsamd_config;
 
-#define TSAMD_FLAG_SPLIT_EPILOGUE 1u /* run the K x 2 epilogue as its own kernel even on one GPU */
-#define TSAMD_FLAG_FINISH_KERNEL 4u  /* add the partial rows up in a follow-up kernel instead of the in-kernel ticket */
+#define TSAMD_FLAG_SPLIT_EPILOGUE 1u /* run the sharded kernel sequence (row sum -> exchange) even on one GPU */
 #define TSAMD_FLAG_NO_GRAPH 2u       /* tsamd_run_schedule launches eagerly instead of replaying a hipGraph */
 
 int tsamd_abi_version(void);
@@ -147,8 +146,10 @@ int tsamd_comm_init(tsamd_ctx *ctx, const uint8_t id[TSAMD_COMM_ID_BYTES]);
  * missing_rate in [0,1) marks entries missing. */
 int tsamd_synth_genotypes(tsamd_ctx *ctx, const double *theta, const double *beta,
                           uint32_t first_loc, uint32_t n_locs, uint64_t seed, double missing_rate);
-/* HIP-event timing of the plain pass kernel launches issued by tsamd_run_schedule:
- * enable, run, then read the launch count and the summed duration. */
+/* HIP-event timing of the kernels issued by tsamd_run_schedule (eager launches while
+ * enabled): per SNP one event pair brackets the first-pass kernel and one brackets the run
+ * of max_inner-1 plain-pass launches.  Enable, run, then read launch counts and summed
+ * bracket durations (a plain-pass bracket includes its inter-kernel gaps). */
 int tsamd_profile_enable(tsamd_ctx *ctx, int on);
 int tsamd_profile_read(tsamd_ctx *ctx, uint64_t *pass_launches, double *pass_ms_total,
                        uint64_t *first_launches, double *first_ms_total);

@@ -10,7 +10,6 @@ _HANDLE = None
 COMM_ID_BYTES = 128
 FLAG_SPLIT_EPILOGUE = 1
 FLAG_NO_GRAPH = 2
-FLAG_FINISH_KERNEL = 4
 
 
 class Config(C.Structure):

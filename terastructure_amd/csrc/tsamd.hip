@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "tsamd.h"
+#define TSAMD_MAIN_TU 1
 #include "tsamd_generic_kernels.h"
 #include "tsamd_kernels.h"
 
@@ -71,11 +72,6 @@ struct HeldLoc {
 constexpr uint32_t kProfCap = 8192;
 constexpr uint32_t kGraphSnps = 16;  // SNPs per captured graph
 
-__global__ void ts_begin_schedule(Ctl *ctl, uint32_t n) {
-  ctl->cursor = 0u;
-  ctl->sched_len = n;
-}
-
 }  // namespace
 
 struct tsamd_ctx {
@@ -101,7 +97,8 @@ struct tsamd_ctx {
   // hipGraph replay of the per-SNP kernel sequence
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
-  uint32_t graph_snps = 0;
+  uint32_t graph_snps = 0, graph_par0 = 0;
+  uint64_t q = 0;  // kernels of the state-machine sequence launched so far (parity = q & 1)
   std::vector<std::vector<uint32_t>> keepalive;  // host schedules of copies possibly still in flight
   std::string err;
 };
@@ -133,7 +130,7 @@ int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
   if (!(ctx)) return TSAMD_EINVAL
 
 // launchers of the K-specialised kernels, one per translation unit (tsamd_inst.hip)
-#define TSAMD_DECL(k) void launch_k##k(int, uint32_t, uint32_t, hipStream_t, const DevParams &);
+#define TSAMD_DECL(k) void launch_k##k(int, uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t);
 #define TSAMD_ALL_K(X)                                                                             \
   X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)     \
   X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
@@ -150,69 +147,76 @@ __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
     p[i] = (i & 1) ? v1 : v0;
 }
 
-void launch_pass(tsamd_ctx *c, bool first) {
-  if (first)
-    kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p);
-  else
-    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p);
-}
+// Every kernel of the state-machine sequence gets the next parity bit (tsamd_device.h).
+uint32_t next_parity(tsamd_ctx *c) { return (uint32_t)(c->q++ & 1u); }
 
-void launch_epilogue(tsamd_ctx *c, bool first) {
-  if (first)
-    hipLaunchKernelGGL((ts_epilogue<true>), dim3(1), dim3(64), 0, c->stream, c->p);
-  else
-    hipLaunchKernelGGL((ts_epilogue<false>), dim3(1), dim3(64), 0, c->stream, c->p);
-}
-
-// one pass = pass kernel [+ finish kernel] [+ all-reduce + epilogue kernel]
-//   tail 0, one GPU : ts_pass (ticket: last workgroup reduces and runs the epilogue)
-//   tail 2, one GPU : ts_pass, ts_finish (reduce + epilogue after the kernel boundary)
-//   sharded / split : ts_pass [, ts_finish] -> ctl->lt, all-reduce -> ctl->lt_sum, ts_epilogue
+// one pass = ts_pass [+ ts_reduce_rows + all-reduce when sharded]
 int enqueue_pass(tsamd_ctx *c, bool first) {
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->prof) {
-    auto &evs = first ? c->ev_first : c->ev_pass;
-    uint32_t &n = first ? c->n_ev_first : c->n_ev_pass;
-    if (n < kProfCap) {
-      if (evs.size() < 2 * (size_t)(n + 1)) {
-        hipEvent_t a, b;
-        HIP_TRY(c, hipEventCreate(&a));
-        HIP_TRY(c, hipEventCreate(&b));
-        evs.push_back(a);
-        evs.push_back(b);
-      }
-      e0 = evs[2 * n];
-      e1 = evs[2 * n + 1];
-      n++;
-      HIP_TRY(c, hipEventRecord(e0, c->stream));
-    }
-  }
-  launch_pass(c, first);
-  if (e1) HIP_TRY(c, hipEventRecord(e1, c->stream));
-  const uint32_t G = first ? c->grid_first : c->grid;
-  if (c->p.tail == 2u) {
-    if (first)
-      hipLaunchKernelGGL((ts_finish<true>), dim3(1), dim3(256), 0, c->stream, c->p, G, c->split ? 1u : 0u);
-    else
-      hipLaunchKernelGGL((ts_finish<false>), dim3(1), dim3(256), 0, c->stream, c->p, G, c->split ? 1u : 0u);
-  }
+  const uint32_t par = next_parity(c);
+  if (first)
+    kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p, par);
+  else
+    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p, par);
   if (c->split) {
+    hipLaunchKernelGGL(ts_reduce_rows, dim3(1), dim3(256), 0, c->stream, c->p, par);
+    Ctl *ctl = c->p.ctl;
     if (c->comm) {
-      ncclResult_t r = g_rccl.AllReduce(c->p.ctl->lt, c->p.ctl->lt_sum, 2 * c->cfg.k, ncclDouble, ncclSum, c->comm,
+      ncclResult_t r = g_rccl.AllReduce(ctl->lt[par], ctl->lt_sum[par], 2 * c->cfg.k, ncclDouble, ncclSum, c->comm,
                                         c->stream);
       if (r != ncclSuccess) return fail(c, TSAMD_ECOMM, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
     } else {
-      HIP_TRY(c, hipMemcpyAsync(c->p.ctl->lt_sum, c->p.ctl->lt, sizeof(double) * 2 * c->cfg.k,
+      HIP_TRY(c, hipMemcpyAsync(ctl->lt_sum[par], ctl->lt[par], sizeof(double) * 2 * c->cfg.k,
                                 hipMemcpyDeviceToDevice, c->stream));
     }
-    launch_epilogue(c, first);
   }
   return TSAMD_OK;
 }
 
+void enqueue_begin(tsamd_ctx *c, uint32_t n, bool drop_pending) {
+  hipLaunchKernelGGL(ts_begin, dim3(1), dim3(64), 0, c->stream, c->p.ctl, n, next_parity(c), 2 * c->cfg.k,
+                     drop_pending ? 1u : 0u);
+}
+
+void enqueue_flush(tsamd_ctx *c) {
+  hipLaunchKernelGGL(ts_flush, dim3(1), dim3(256), 0, c->stream, c->p, next_parity(c));
+}
+
+// profiling: one HIP-event pair around the first pass and one around the run of plain
+// passes of each SNP (a bracket per launch would mostly time the dispatch gap of an
+// eagerly launched ~10 us kernel)
+int prof_event(tsamd_ctx *c, std::vector<hipEvent_t> &evs, uint32_t slot, hipEvent_t *out) {
+  while (evs.size() <= slot) {
+    hipEvent_t e;
+    HIP_TRY(c, hipEventCreate(&e));
+    evs.push_back(e);
+  }
+  *out = evs[slot];
+  return TSAMD_OK;
+}
+
 int enqueue_snp(tsamd_ctx *c) {
+  const bool prof = c->prof && c->n_ev_first < kProfCap;
+  hipEvent_t e = nullptr;
+  if (prof) {
+    if (int rc = prof_event(c, c->ev_first, 2 * c->n_ev_first, &e)) return rc;
+    HIP_TRY(c, hipEventRecord(e, c->stream));
+  }
   int rc = enqueue_pass(c, true);
+  if (prof) {
+    if (int rc2 = prof_event(c, c->ev_first, 2 * c->n_ev_first + 1, &e)) return rc2;
+    HIP_TRY(c, hipEventRecord(e, c->stream));
+    c->n_ev_first++;
+    if (c->cfg.max_inner > 1) {
+      if (int rc2 = prof_event(c, c->ev_pass, 2 * c->n_ev_pass, &e)) return rc2;
+      HIP_TRY(c, hipEventRecord(e, c->stream));
+    }
+  }
   for (uint32_t i = 1; rc == TSAMD_OK && i < c->cfg.max_inner; ++i) rc = enqueue_pass(c, false);
+  if (prof && c->cfg.max_inner > 1 && rc == TSAMD_OK) {
+    if (int rc2 = prof_event(c, c->ev_pass, 2 * c->n_ev_pass + 1, &e)) return rc2;
+    HIP_TRY(c, hipEventRecord(e, c->stream));
+    c->n_ev_pass++;
+  }
   return rc;
 }
 
@@ -228,6 +232,7 @@ void destroy_graph(tsamd_ctx *c) {
 // (location, pending state) from device memory, so the graph is replayable as is.
 int build_graph(tsamd_ctx *c, uint32_t snps) {
   destroy_graph(c);
+  c->graph_par0 = (uint32_t)(c->q & 1u);  // kernel arguments (parity bits) are frozen at capture
   HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = TSAMD_OK;
   for (uint32_t s = 0; s < snps && rc == TSAMD_OK; ++s) rc = enqueue_snp(c);
@@ -409,7 +414,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
     const char *s = getenv(name);
     return (s && *s) ? (uint32_t)std::max(0, atoi(s)) : dflt;
   };
-  uint32_t block = env_u32("TSAMD_BLOCK", 256);
+  uint32_t block = env_u32("TSAMD_BLOCK", cfg->k <= 16 ? 512 : 256);
   if (block != 256u && block != 512u && block != 1024u) block = 256u;
   if (block == 1024u && cfg->k > 8) block = 512u;  // register budget of the pipelined loop
   auto geometry = [&](uint32_t nitems, uint32_t blk, uint32_t target, uint32_t &chunk, uint32_t &grid) {
@@ -422,11 +427,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   c->first_vec = env_u32("TSAMD_FIRST_VEC", 1) == 2 ? 2 : 1;
   geometry(p.npairs, block, env_u32("TSAMD_GRID", 256), p.chunk, c->grid);
   geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", 512), p.chunk_first, c->grid_first);
-  {
-    const uint32_t dflt = (cfg->flags & TSAMD_FLAG_FINISH_KERNEL) ? 2u : 0u;
-    const uint32_t mode = env_u32("TSAMD_TAIL", dflt);
-    p.tail = (mode == 2u) ? 2u : (c->split ? 1u : 0u);
-  }
+  p.rows_from_lt = c->split ? 1u : 0u;
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
   CREATE_TRY(hipMalloc((void **)&p.w, K * np * sizeof(double)));
@@ -435,7 +436,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   CREATE_TRY(hipMalloc((void **)&p.lam, L * K * 2 * sizeof(double)));
   CREATE_TRY(hipMalloc((void **)&p.eb, L * K * 2 * sizeof(double)));
   CREATE_TRY(hipMalloc((void **)&p.ctl, sizeof(Ctl)));
-  CREATE_TRY(hipMalloc((void **)&p.partials, (size_t)kMaxGrid * 2 * TSAMD_MAX_K * sizeof(double)));
+  CREATE_TRY(hipMalloc((void **)&p.partials, (size_t)2 * kMaxGrid * 2 * TSAMD_MAX_K * sizeof(double)));
   c->sched_cap = 1024;
   CREATE_TRY(hipMalloc((void **)&c->d_sched, c->sched_cap * sizeof(uint32_t)));
   p.sched = c->d_sched;
@@ -443,7 +444,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   CREATE_TRY(hipMemsetAsync(p.bed, 0x55, L * p.colstride, c->stream));  // all missing
   CREATE_TRY(hipMemsetAsync(p.cnt, 0, np * sizeof(uint32_t), c->stream));
   CREATE_TRY(hipMemsetAsync(p.ctl, 0, sizeof(Ctl), c->stream));
-  CREATE_TRY(hipMemsetAsync(p.partials, 0, (size_t)kMaxGrid * 2 * TSAMD_MAX_K * sizeof(double), c->stream));
+  CREATE_TRY(hipMemsetAsync(p.partials, 0, (size_t)2 * kMaxGrid * 2 * TSAMD_MAX_K * sizeof(double), c->stream));
   hipLaunchKernelGGL(ts_fill_f64, dim3(1024), dim3(256), 0, c->stream, p.gam, K * np, 1.0, 1.0);
   hipLaunchKernelGGL(ts_fill_f64, dim3(1024), dim3(256), 0, c->stream, p.w, K * np, 1.0, 1.0);
   // init_lambda (src/snpsamplinge.cc:239-250): lambda = eta, Elogbeta = psi(eta_t) - psi(eta0 + eta1)
@@ -575,7 +576,7 @@ int tsamd_set_gamma(tsamd_ctx *c, const double *gamma) {
     if (!(gamma[i] > 0.0) || !std::isfinite(gamma[i])) return fail(c, TSAMD_EINVAL, "gamma[%zu] must be positive and finite", i);
   HIP_TRY(c, hipSetDevice(c->dev));
   if (int rc = upload_kmajor(c, gamma, c->p.gam, 1.0)) return rc;
-  kLaunchers[c->cfg.k](kLaunchRefresh, 0, 0, c->stream, c->p);
+  kLaunchers[c->cfg.k](kLaunchRefresh, 0, 0, c->stream, c->p, 0);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSAMD_OK;
@@ -699,19 +700,22 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   }
   HIP_TRY(c, hipMemcpyAsync(c->d_sched, ent.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   c->keepalive.push_back(std::move(ent));  // until the next tsamd_synchronize
-  hipLaunchKernelGGL(ts_begin_schedule, dim3(1), dim3(1), 0, c->stream, c->p.ctl, n);
-  // everything that varies per SNP is read from device memory, so one captured
-  // sequence of kGraphSnps SNPs is replayed as often as needed; kernels past the
-  // end of the schedule return immediately.
+  enqueue_begin(c, n, false);
+  // Everything that varies per SNP is read from device memory, so one captured sequence
+  // of kGraphSnps SNPs is replayed as often as needed; kernels past the end of the
+  // schedule only carry the state forward.  (kGraphSnps is even, so a replay keeps the
+  // launch parity.)
   const bool use_graph = !(c->cfg.flags & TSAMD_FLAG_NO_GRAPH) && !c->comm && !c->prof && n >= kGraphSnps;
   if (use_graph) {
     if (!c->graph_exec)
       if (int rc = build_graph(c, kGraphSnps)) return rc;
+    if ((uint32_t)(c->q & 1u) != c->graph_par0) enqueue_begin(c, 0xffffffffu, false);  // re-align parity
     for (uint32_t i = 0; i < n; i += kGraphSnps) HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
-    return TSAMD_OK;
+  } else {
+    for (uint32_t i = 0; i < n; ++i)
+      if (int rc = enqueue_snp(c)) return rc;
   }
-  for (uint32_t i = 0; i < n; ++i)
-    if (int rc = enqueue_snp(c)) return rc;
+  enqueue_flush(c);
   HIP_TRY(c, hipGetLastError());
   return TSAMD_OK;
 }
@@ -726,7 +730,7 @@ int tsamd_synchronize(tsamd_ctx *c) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, c->ev_pass[2 * i], c->ev_pass[2 * i + 1]) == hipSuccess) {
         c->prof_pass_ms += ms;
-        c->prof_pass_n++;
+        c->prof_pass_n += c->cfg.max_inner - 1;  // launches inside the bracket
       }
     }
     for (uint32_t i = 0; i < c->n_ev_first; ++i) {
@@ -765,7 +769,7 @@ int tsamd_total_passes(tsamd_ctx *c, uint64_t *passes) {
 int tsamd_clear_pending(tsamd_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->dev));
-  HIP_TRY(c, hipMemsetAsync(&c->p.ctl->pend_do, 0, sizeof(uint32_t), c->stream));
+  enqueue_begin(c, 0xffffffffu, true);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSAMD_OK;
 }
@@ -831,7 +835,7 @@ int tsamd_comm_init(tsamd_ctx *c, const uint8_t id[TSAMD_COMM_ID_BYTES]) {
     return fail(c, TSAMD_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
   }
   c->split = true;
-  if (c->p.tail == 0u) c->p.tail = 1u;
+  c->p.rows_from_lt = 1u;
   destroy_graph(c);
   return TSAMD_OK;
 }

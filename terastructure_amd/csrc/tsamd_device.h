@@ -20,34 +20,43 @@ namespace tsamd {
 constexpr int kBlock = 256;       // threads per workgroup of the generic kernels
 constexpr int kMaxGrid = 2048;    // upper bound on pass-kernel workgroups
 
-// Device-resident control block: everything the stream-ordered kernels need to
-// agree on without a host round trip.
+// Device-resident state machine.  No workgroup ever reads a word that another workgroup
+// of the SAME launch writes: every kernel of the stream-ordered sequence carries a parity
+// bit (a launch-time constant), reads State/rows of slot parity^1 and writes slot parity.
+// So there are no tickets, atomics or fences in the hot path; every workgroup recomputes
+// the tiny K x 2 epilogue of the previous pass redundantly from the same partial rows, in
+// the same order, and therefore reaches the same decision.
+struct State {
+  uint32_t idx;    // schedule index of the SNP described here; 0xffffffff: none started in this schedule
+  uint32_t valid;  // an SNP has been started (its gamma step is pending unless hol)
+  uint32_t loc, hol;
+  uint32_t iters;  // passes run for it; the partial rows of pass `iters` are pending unless done
+  uint32_t done;   // SNP complete: lam[loc] / eb[loc] in the global arrays are final
+  uint32_t nrows;  // partial rows written by pass `iters`
+  uint32_t pad;
+  double lam[2 * TSAMD_MAX_K];  // !done: lambda[loc] before the pending pass' epilogue
+  double eb[2 * TSAMD_MAX_K];   // exp(Elogbeta[loc]) used by pass `iters` (the last executed pass)
+};
+
 struct Ctl {
-  uint32_t cursor;     // index into the schedule of the NEXT SNP to start
-  uint32_t sched_len;  // entries in the schedule; kernels past the end are no-ops
-  uint32_t done;       // current SNP converged (mean |dlambda| < thresh)
-  uint32_t iters;      // passes executed for the current SNP
-  uint32_t ticket;     // arrival counter of the running pass kernel
-  uint32_t pend_do;    // previous SNP has a pending gamma step (it ran with hol_mode == 0)
-  uint32_t pend_loc;   // its location
-  uint32_t last_iters; // inner passes of the most recently finished SNP (for snp_update)
+  uint32_t sched_len;   // entries in the schedule; kernels past the end only carry state forward
+  uint32_t last_iters;  // inner passes of the most recently completed SNP (for tsamd_snp_update)
   unsigned long long total_passes;
-  unsigned long long pad1;
-  double eb_stale[2 * TSAMD_MAX_K]; // exp(Elogbeta) used by the LAST executed pass of the pending SNP
-  double lt[2 * TSAMD_MAX_K];       // this shard's lambda_t (multi-GPU: all-reduce input)
-  double lt_sum[2 * TSAMD_MAX_K];   // all-reduced lambda_t
+  State st[2];
+  double lt[2][2 * TSAMD_MAX_K];      // sharded: this shard's summed partial rows (all-reduce input)
+  double lt_sum[2][2 * TSAMD_MAX_K];  // all-reduced; read as the single "row" of the previous pass
 };
 
 struct DevParams {
   uint8_t *bed;        // [l][colstride] 2-bit PLINK codes, shard-local, padding = missing
-  uint64_t colstride;  // bytes per column (multiple of 64)
+  uint64_t colstride;  // bytes per column (multiple of 128)
   double *w;           // [K][npad]  exp(Elogtheta - rowmax)
   double *gam;         // [K][npad]
   uint32_t *cnt;       // [npad]     c_n
   double *lam;         // [l][K][2]
   double *eb;          // [l][K][2]  exp(Elogbeta)
   Ctl *ctl;
-  double *partials;    // [grid][2K]
+  double *partials;    // [2][kMaxGrid][2K] partial rows, slot = launch parity
   const uint32_t *sched; // entries: loc | hol_mode << 31
   uint32_t npad;       // padded individuals (multiple of 512)
   uint32_t npairs;     // npad / 2
@@ -55,9 +64,7 @@ struct DevParams {
   uint32_t chunk_first; // items (individuals, or pairs with TSAMD_FIRST_VEC=2) per workgroup of the first pass
   uint32_t K;
   uint32_t max_inner;
-  uint32_t tail;       // how a pass ends: 0 = ticket, last workgroup reduces + runs the epilogue;
-                       // 1 = ticket, last workgroup leaves lambda_t in ctl->lt (all-reduce follows);
-                       // 2 = nothing: the ts_finish kernel that follows adds the partial rows up
+  uint32_t rows_from_lt; // sharded: the previous pass' rows are the one all-reduced row ctl->lt_sum[parity^1]
   double alpha, eta0, eta1, nodetau0, nodekappa, gamma_scale, thresh;
 };
 
@@ -89,6 +96,43 @@ __device__ __forceinline__ double digamma(double x) {
   t = fma(f, t, -1.0 / 12.0);
   const double tail = log(z) - 0.5 * rz + f * t;
   return big ? tail : tail - num / den;
+}
+
+// exp(psi(x)) split as A * exp(-r): A = z * exp(u(z)), z = x + 10,
+// u = -1/(2z) - sum B2n/(2n z^2n) (|u| <= 0.051, so exp(u) is an 8th-degree Taylor
+// polynomial, relative error < 1e-17) and r = sum_{i<10} 1/(x+i) = P'(x)/P(x).
+// Lets the gamma step form w[k] = A_k * exp(r_min - r_k) -- exp(Elogtheta) up to a
+// per-individual factor -- with one exp and no log per population.
+__device__ __forceinline__ void exp_digamma_parts(double x, double &A, double &r) {
+  double num = 0.0, den = 1.0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const double xi = x + (double)i;
+    num = fma(num, xi, den);
+    den *= xi;
+  }
+  r = num / den;
+  const double z = x + 10.0;
+  const double rz = 1.0 / z;
+  const double f = rz * rz;
+  double t = -1.0 / 12.0;
+  t = fma(f, t, 691.0 / 32760.0);
+  t = fma(f, t, -1.0 / 132.0);
+  t = fma(f, t, 1.0 / 240.0);
+  t = fma(f, t, -1.0 / 252.0);
+  t = fma(f, t, 1.0 / 120.0);
+  t = fma(f, t, -1.0 / 12.0);
+  const double u = fma(f, t, -0.5 * rz);
+  double e = 1.0 / 40320.0;
+  e = fma(u, e, 1.0 / 5040.0);
+  e = fma(u, e, 1.0 / 720.0);
+  e = fma(u, e, 1.0 / 120.0);
+  e = fma(u, e, 1.0 / 24.0);
+  e = fma(u, e, 1.0 / 6.0);
+  e = fma(u, e, 0.5);
+  e = fma(u, e, 1.0);
+  e = fma(u, e, 1.0);
+  A = z * e;
 }
 
 // v from lane (lane ^ OFF).  OFF < 32: ds_swizzle bit mode (no address register, no
@@ -170,14 +214,6 @@ __device__ __forceinline__ double uniform_f64(double v) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
-// agent-scope accessors for data handed between workgroups inside one launch
-__device__ __forceinline__ void st_agent(double *p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_agent(const double *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace tsamd

@@ -1,81 +1,136 @@
 // HIP kernels of the SNP-minibatch SVI engine (gfx950).  See tsamd_device.h for
-// the formulation and DESIGN.md for layouts and rooflines.
+// the formulation / state machine and DESIGN.md for layouts and rooflines.
 //
-// Kernels (all stream-ordered, no host round trip between them):
-//   ts_pass<KT, FIRST>   one inner pass over the shard's individuals for the current
-//                        SNP: phi for both parents + lambda_t accumulation, deterministic
-//                        block/grid reduction, and (single GPU) the K x 2 epilogue run by
-//                        the last-arriving workgroup.  FIRST also applies the pending
-//                        gamma/Elogtheta step of the previous SNP in the same sweep.
-//   ts_epilogue<FIRST>   the K x 2 epilogue alone (multi-GPU: after the all-reduce).
-//   ts_refresh_w<KT>     w = exp(psi(gamma) - rowmax) after tsamd_set_gamma.
-//   ts_export_indiv      gamma / theta / Elogtheta as row-major [n][K].
-//   ts_export_loc        Ebeta / Elogbeta from lambda.
-//   ts_heldout_*         validation-mask fold and held-out log-likelihood terms.
-//   ts_synth             synthetic PSD genotypes written straight into HBM.
+// Kernels (all stream-ordered, no host round trip, no inter-workgroup hand-off):
+//   ts_pass<K, FIRST, BLOCK, VEC>(p, parity)
+//        prologue (every workgroup, redundantly): add up the partial rows of the previous
+//        pass in a fixed order and run its K x 2 epilogue (update_lambda, estimate_beta,
+//        convergence test); then one inner pass over the shard's individuals for the
+//        current SNP: phi for both parents + lambda_t accumulation -> one partial row per
+//        workgroup.  FIRST starts the next SNP of the schedule and applies the previous
+//        SNP's gamma/Elogtheta step in the same sweep.
+//   ts_flush(p, parity)       completes the pending pass (end of a schedule)
+//   ts_begin(ctl, n, parity)  starts a schedule
+//   ts_reduce_rows(p, parity) sharded: row sum -> ctl->lt for the all-reduce
+//   ts_refresh_w<K>           w = exp(psi(gamma) - rowmax) after tsamd_set_gamma
 #pragma once
 #include "tsamd_device.h"
 
 namespace tsamd {
 
 // ---------------------------------------------------------------------------
-// K x 2 epilogue of one pass: update_lambda + estimate_beta + convergence test
-// (src/snpsamplinge.cc:356-364, :267-296; abs_mean src/matrix.hh:885-893).
-// Called by every thread of ONE workgroup; thread j < 2K owns lambda[loc][j/2][j%2].
-// lt = this thread's all-individual lambda_t[j];  ebj = exp(Elogbeta) this pass used.
-template <bool FIRST>
-__device__ __forceinline__ void epilogue_block(const DevParams &p, Ctl *ctl, uint32_t cur, uint32_t loc,
-                                               uint32_t hol, double lt, double ebj, double *s_lam,
-                                               double *s_diff) {
+// Finish the pending pass described by S: lambda_t[j] = eb_used[j] * sum_rows, then
+// update_lambda + estimate_beta + convergence test (src/snpsamplinge.cc:356-364,
+// :267-296; abs_mean src/matrix.hh:885-893).  Called by ALL threads of a workgroup.
+// Fixed summation order: thread (r, j) adds rows r, r+R, ... (R = BLOCK / J), then
+// r = 0..R-1.  Outputs in LDS: s_lam = new lambda[loc], s_eb = new exp(Elogbeta[loc]).
+// Returns (uniformly) whether the SNP is complete (converged or max_inner passes run).
+template <int BLOCK>
+__device__ __forceinline__ bool finish_pending(const DevParams &p, const State *S, const double *rows,
+                                               uint32_t nrows, uint32_t J, double *s_fin, double *s_lam,
+                                               double *s_eb, double *s_diff, uint32_t *s_flag) {
   const uint32_t tid = threadIdx.x;
-  const uint32_t J = 2 * p.K;
+  const uint32_t R = BLOCK / J;
+  const uint32_t j = tid % J, r = tid / J;
+  double v = 0.0;
+  if (r < R) {
+    for (uint32_t g0 = r; g0 < nrows; g0 += 8u * R) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = rows[(size_t)min(g0 + (uint32_t)u * R, nrows - 1u) * J + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += (g0 + (uint32_t)u * R < nrows) ? t[u] : 0.0;
+    }
+  }
+  s_fin[tid] = v;
+  __syncthreads();
   double nw = 0.0;
   if (tid < J) {
-    double *lam = p.lam + (size_t)loc * J;
-    const double old = lam[tid];
+    double lt = 0.0;
+    for (uint32_t rr = 0; rr < R; ++rr) lt += s_fin[rr * J + tid];
+    lt *= S->eb[tid];  // the b[k,t] factored out of the accumulation
+    const double old = S->lam[tid];
     nw = ((tid & 1u) ? p.eta1 : p.eta0) + lt;
-    lam[tid] = nw;
     s_lam[tid] = nw;
     s_diff[tid] = fabs(nw - old);
   }
   __syncthreads();
   if (tid < J) {
     const double s = s_lam[tid & ~1u] + s_lam[tid | 1u];
-    const double el = digamma(nw) - digamma(s);
-    ctl->eb_stale[tid] = ebj;
-    p.eb[(size_t)loc * J + tid] = exp(el);
+    s_eb[tid] = exp(digamma(nw) - digamma(s));
   }
   if (tid == 0) {
     double d = 0.0;
-    for (uint32_t j = 0; j < J; ++j) d += s_diff[j];
+    for (uint32_t jj = 0; jj < J; ++jj) d += s_diff[jj];
     d /= (double)J;
-    const uint32_t it = FIRST ? 1u : ctl->iters + 1u;
-    const uint32_t conv = (d < p.thresh) ? 1u : 0u;
-    ctl->iters = it;
-    ctl->done = (conv || it >= p.max_inner) ? 1u : 0u;
-    ctl->last_iters = it;
-    ctl->total_passes += 1ull;
-    if (FIRST) {
-      ctl->pend_loc = loc;
-      ctl->pend_do = hol ? 0u : 1u;
-      ctl->cursor = cur + 1u;
+    *s_flag = (d < p.thresh || S->iters >= p.max_inner) ? 1u : 0u;
+  }
+  __syncthreads();
+  return *s_flag != 0u;
+}
+
+// workgroup 0 publishes the completed SNP: final lambda / exp(Elogbeta) into the global
+// arrays, counters, and the carried-forward state (eb stays the one the LAST executed
+// pass used: the deferred gamma step needs it, src/snpsamplinge.cc:660-668).
+__device__ __forceinline__ void publish_complete(const DevParams &p, Ctl *ctl, const State *S, State *W,
+                                                 uint32_t J, const double *s_lam, const double *s_eb,
+                                                 bool write_state) {
+  const uint32_t tid = threadIdx.x;
+  if (tid < J) {
+    p.lam[(size_t)S->loc * J + tid] = s_lam[tid];
+    p.eb[(size_t)S->loc * J + tid] = s_eb[tid];
+    if (write_state) {
+      W->lam[tid] = s_lam[tid];
+      W->eb[tid] = S->eb[tid];
+    }
+  }
+  if (tid == 0) {
+    ctl->last_iters = S->iters;
+    ctl->total_passes += (unsigned long long)S->iters;
+    if (write_state) {
+      W->idx = S->idx;
+      W->valid = 1u;
+      W->loc = S->loc;
+      W->hol = S->hol;
+      W->iters = S->iters;
+      W->done = 1u;
+      W->nrows = 0u;
     }
   }
 }
 
-// w[k] = exp(psi(g[k]) - max_j psi(g[j])): Elogtheta up to a per-individual constant,
-// which cancels in phi (estimate_theta, src/snpsamplinge.cc:721-740).
+__device__ __forceinline__ void carry_state(const State *S, State *W, uint32_t J) {
+  const uint32_t tid = threadIdx.x;
+  if (tid < J) {
+    W->lam[tid] = S->lam[tid];
+    W->eb[tid] = S->eb[tid];
+  }
+  if (tid == 0) {
+    W->idx = S->idx;
+    W->valid = S->valid;
+    W->loc = S->loc;
+    W->hol = S->hol;
+    W->iters = S->iters;
+    W->done = S->done;
+    W->nrows = S->nrows;
+  }
+}
+
+// w[k] = exp(psi(g[k])) * exp(r_min) = A_k * exp(r_min - r_k): Elogtheta exponentiated
+// up to a per-individual constant, which cancels in phi (estimate_theta,
+// src/snpsamplinge.cc:721-740).  The largest-gamma population gets exp(0), so w never
+// underflows for all k at once.
 template <int KT>
 __device__ __forceinline__ void gamma_to_w(const double (&g)[KT], double (&w)[KT]) {
-  double ps[KT];
-  double mx = -1.0e300;
+  double A[KT], r[KT];
+  double rmin = 1.0e300;
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
-    ps[k] = digamma(g[k]);
-    mx = fmax(mx, ps[k]);
+    exp_digamma_parts(g[k], A[k], r[k]);
+    rmin = fmin(rmin, r[k]);
   }
 #pragma unroll
-  for (int k = 0; k < KT; ++k) w[k] = exp(ps[k] - mx);
+  for (int k = 0; k < KT; ++k) w[k] = A[k] * exp(rmin - r[k]);
 }
 
 // SVI step for one individual (update_gamma + update_rho_indiv,
@@ -124,44 +179,107 @@ struct Lanes<2> {
   static __device__ __forceinline__ C pack_c(const uint32_t (&o)[2]) { return make_uint2(o[0], o[1]); }
 };
 
-// One inner pass for the current SNP.  KT == K exactly (one instantiation per K), so
-// every k-loop is straight-line code and the K row loads of an iteration are issued
-// back to back.  Item i of a workgroup's chunk is VEC consecutive individuals: one
-// 8*VEC-byte load per population row and 2*VEC bits of the 2-bit column.  The plain
-// pass uses VEC = 2; the first pass, which also carries the gamma step, uses VEC = 1 to
-// halve its register footprint.
+// One inner pass.  KT == K exactly (one instantiation per K), so every k-loop is
+// straight-line code and the K row loads of an iteration are issued back to back.
+// Item i of a workgroup's chunk is VEC consecutive individuals: one 8*VEC-byte load per
+// population row and 2*VEC bits of the 2-bit column.  The plain pass uses VEC = 2; the
+// first pass, which also carries the gamma step, uses VEC = 1 to halve its registers.
 template <int KT, bool FIRST, int BLOCK, int VEC>
-__global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p) {
+__global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par) {
   constexpr int kWaves = BLOCK / 64;
   using LN = Lanes<VEC>;
   using WT = typename LN::T;
   constexpr uint32_t kItemsPerWord = 16u / VEC;  // items per 32-bit word of the column
   constexpr uint32_t kCodeBits = 2u * VEC;
-  __shared__ double s_eb[2 * KT];
-  __shared__ double s_sb[2 * KT];
-  __shared__ double s_red[kWaves][2 * KT];
+  constexpr uint32_t J = 2 * KT;
+  __shared__ double s_eb[J];    // exp(Elogbeta) this pass uses
+  __shared__ double s_lam[J];   // lambda[loc] before this pass' epilogue
+  __shared__ double s_sb[J];    // FIRST: exp(Elogbeta) of the previous SNP's last pass
+  __shared__ double s_plam[J];  // FIRST: final lambda / eb of the previous SNP when finished here
+  __shared__ double s_peb[J];
+  __shared__ double s_diff[J];
+  __shared__ double s_red[kWaves][J];
   __shared__ double s_fin[BLOCK];
-  __shared__ double s_lam[2 * KT];
-  __shared__ double s_diff[2 * KT];
-  __shared__ uint32_t s_last;
+  __shared__ uint32_t s_flag;
 
   Ctl *ctl = p.ctl;
+  const State *S = &ctl->st[par ^ 1u];
+  State *W = &ctl->st[par];
   const uint32_t tid = threadIdx.x;
-  constexpr uint32_t J = 2 * KT;
-  const uint32_t cur = ctl->cursor;
-  const uint32_t idx = FIRST ? cur : cur - 1u;
-  if (idx >= ctl->sched_len) return;
-  if (!FIRST && ctl->done) return;
-  const uint32_t ent = p.sched[idx];
-  const uint32_t loc = ent & 0x7fffffffu, hol = ent >> 31;
-  const bool do_gamma = FIRST && ctl->pend_do != 0u;
-  const uint32_t prev_loc = ctl->pend_loc;
+  const size_t np = p.npad;
+  const uint32_t nitems = p.npad / VEC;
+  const uint32_t chunk = FIRST ? p.chunk_first : p.chunk;
+  const uint32_t begin = blockIdx.x * chunk;
+  const uint32_t end = min(begin + chunk, nitems);
 
-  if (tid < J) {
-    s_eb[tid] = p.eb[(size_t)loc * J + tid];
-    if (do_gamma) s_sb[tid] = ctl->eb_stale[tid];
+  auto load_rows = [&](uint32_t i, WT (&wv)[KT]) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) wv[k] = reinterpret_cast<const WT *>(p.w + (size_t)k * np)[i];
+  };
+
+  // the first item's row loads do not depend on the state machine: get them in flight
+  // before the prologue's dependent loads
+  WT bufA[KT];
+  const uint32_t i0 = begin + tid;
+  if (!FIRST && i0 < end) load_rows(i0, bufA);
+  __builtin_amdgcn_sched_barrier(0);
+
+  const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
+  const uint32_t siters = S->iters, snrows = S->nrows;
+  const uint32_t sched_len = ctl->sched_len;
+  const double *rowsR = p.rows_from_lt ? ctl->lt_sum[par ^ 1u] : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
+  const uint32_t nrowsR = p.rows_from_lt ? 1u : snrows;
+  double *rowsW = p.partials + (size_t)par * kMaxGrid * J;
+
+  const bool pending = svalid != 0u && sdone == 0u;
+  uint32_t loc, hol, idx, iters;
+  bool do_gamma = false;
+  uint32_t prev_loc = 0;
+
+  if constexpr (!FIRST) {
+    if (!pending) {  // nothing in flight (converged earlier, or schedule exhausted): carry state
+      if (blockIdx.x == 0) carry_state(S, W, J);
+      return;
+    }
+    const bool complete = finish_pending<BLOCK>(p, S, rowsR, nrowsR, J, s_fin, s_lam, s_eb, s_diff, &s_flag);
+    if (complete) {
+      if (blockIdx.x == 0) publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
+      return;
+    }
+    loc = sloc;
+    hol = shol;
+    idx = sidx;
+    iters = siters + 1u;
+  } else {
+    idx = sidx + 1u;  // 0xffffffff + 1 = 0: first SNP of the schedule
+    if (pending) finish_pending<BLOCK>(p, S, rowsR, nrowsR, J, s_fin, s_plam, s_peb, s_diff, &s_flag);
+    if (idx >= sched_len) {  // schedule exhausted: complete what is pending, carry state
+      if (blockIdx.x == 0) {
+        if (pending)
+          publish_complete(p, ctl, S, W, J, s_plam, s_peb, true);
+        else
+          carry_state(S, W, J);
+      }
+      return;
+    }
+    const uint32_t ent = p.sched[idx];
+    loc = ent & 0x7fffffffu;
+    hol = ent >> 31;
+    iters = 1u;
+    do_gamma = svalid != 0u && shol == 0u;
+    prev_loc = sloc;
+    if (tid < J) {
+      s_sb[tid] = S->eb[tid];
+      if (pending && sloc == loc) {  // same location twice in a row: its final values are still local
+        s_lam[tid] = s_plam[tid];
+        s_eb[tid] = s_peb[tid];
+      } else {
+        s_lam[tid] = p.lam[(size_t)loc * J + tid];
+        s_eb[tid] = p.eb[(size_t)loc * J + tid];
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   double b0[KT], b1[KT];  // wave-uniform: kept in SGPRs
 #pragma unroll
@@ -175,18 +293,8 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p) {
 
   const uint32_t *col = reinterpret_cast<const uint32_t *>(p.bed + (size_t)loc * p.colstride);
   const uint32_t *pcol = reinterpret_cast<const uint32_t *>(p.bed + (size_t)prev_loc * p.colstride);
-  const uint32_t nitems = p.npad / VEC;
-  const uint32_t chunk = FIRST ? p.chunk_first : p.chunk;
-  const uint32_t begin = blockIdx.x * chunk;
-  const uint32_t end = min(begin + chunk, nitems);
-  const size_t np = p.npad;
 
   // ---- main sweep -------------------------------------------------------------------
-  auto load_w = [&](uint32_t i, WT (&wv)[KT], uint32_t &word) {
-#pragma unroll
-    for (int k = 0; k < KT; ++k) wv[k] = reinterpret_cast<const WT *>(p.w + (size_t)k * np)[i];
-    word = col[i / kItemsPerWord];  // lanes share addresses
-  };
   auto accumulate = [&](uint32_t i, const double (&w)[VEC][KT], uint32_t word) {
     const uint32_t code = word >> (kCodeBits * (i % kItemsPerWord));
     double c0[VEC], c1[VEC];
@@ -223,28 +331,32 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p) {
   };
 
   if constexpr (!FIRST) {
-    // two-stage software pipeline: the next iteration's K row loads are in flight while
-    // the current one is reduced
+    // two-stage software pipeline: the next item's K row loads are in flight while the
+    // current one is reduced (prefetch addresses are clamped, not predicated, so the
+    // load/wait counts are static)
     auto consume = [&](uint32_t i, const WT (&wv)[KT], uint32_t word) {
       double w[VEC][KT];
       unpack_rows(wv, w);
       accumulate(i, w, word);
     };
-    // (prefetch addresses are clamped, not predicated, so the load/wait counts are static)
-    WT bufA[KT], bufB[KT];
+    WT bufB[KT];
     uint32_t wordA = 0, wordB = 0;
-    uint32_t i = begin + tid;
+    uint32_t i = i0;
     if (i < end) {
-      load_w(i, bufA, wordA);
+      wordA = col[i / kItemsPerWord];
       while (true) {
         const uint32_t i1 = i + BLOCK;
-        load_w(i1 < end ? i1 : i, bufB, wordB);
+        const uint32_t j1 = i1 < end ? i1 : i;
+        load_rows(j1, bufB);
+        wordB = col[j1 / kItemsPerWord];
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
         consume(i, bufA, wordA);
         __builtin_amdgcn_sched_barrier(0);
         if (i1 >= end) break;
         const uint32_t i2 = i1 + BLOCK;
-        load_w(i2 < end ? i2 : i1, bufA, wordA);
+        const uint32_t j2 = i2 < end ? i2 : i1;
+        load_rows(j2, bufA);
+        wordA = col[j2 / kItemsPerWord];
         __builtin_amdgcn_sched_barrier(0);
         consume(i1, bufB, wordB);
         __builtin_amdgcn_sched_barrier(0);
@@ -259,10 +371,10 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p) {
       sb0[k] = do_gamma ? uniform_f64(s_sb[2 * k]) : 0.0;
       sb1[k] = do_gamma ? uniform_f64(s_sb[2 * k + 1]) : 0.0;
     }
-    for (uint32_t i = begin + tid; i < end; i += BLOCK) {
+    for (uint32_t i = i0; i < end; i += BLOCK) {
       WT wv[KT];
-      uint32_t word;
-      load_w(i, wv, word);
+      load_rows(i, wv);
+      const uint32_t word = col[i / kItemsPerWord];
       double w[VEC][KT];
       if (do_gamma) {
         WT gv[KT];
@@ -326,119 +438,97 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p) {
     double v = s_red[0][tid];
 #pragma unroll
     for (int wv = 1; wv < kWaves; ++wv) v += s_red[wv][tid];
-    if (p.tail == 2u)
-      p.partials[(size_t)blockIdx.x * J + tid] = v;
-    else
-      st_agent(p.partials + (size_t)blockIdx.x * J + tid, v);
+    rowsW[(size_t)blockIdx.x * J + tid] = v;  // read by the NEXT launch only
   }
-  if (p.tail == 2u) return;  // ts_finish (next kernel) adds the partial rows up
-  // hand-off to the last-arriving workgroup.  The partial rows are written through to
-  // the coherence point (agent-scope sc1 stores) and read back with agent-scope loads, so
-  // no L2 write-back / L1 invalidate is needed: every storing wave drains its stores,
-  // the workgroup barrier orders them before lane 0's arrival on the ticket, and the
-  // last arriver reads the rows only after its ticket value has returned.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    const uint32_t t = __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == gridDim.x - 1u) ? 1u : 0u;
-  }
-  __syncthreads();
-  asm volatile("" ::: "memory");
-  if (!s_last) return;
 
-  // grid reduction by the last workgroup, fixed order: thread (r, j) sums
-  // partials[g][j] for g = r, r+R, ... (loads batched 8 deep); then r = 0..R-1.
-  constexpr uint32_t R = BLOCK / J;  // J <= 64 -> R >= 4
-  const uint32_t j = tid % J, r = tid / J;
-  const uint32_t G = gridDim.x;
-  double v = 0.0;
-  if (r < R) {
-    for (uint32_t g0 = r; g0 < G; g0 += 8u * R) {
-      double t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const uint32_t g = g0 + (uint32_t)u * R;
-        t[u] = ld_agent(p.partials + (size_t)min(g, G - 1u) * J + j);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v += (g0 + (uint32_t)u * R < G) ? t[u] : 0.0;
+  // workgroup 0 publishes the state the next launch starts from
+  if (blockIdx.x == 0) {
+    if (FIRST && pending) publish_complete(p, ctl, S, W, J, s_plam, s_peb, false);
+    if (tid < J) {
+      W->lam[tid] = s_lam[tid];
+      W->eb[tid] = s_eb[tid];
+    }
+    if (tid == 0) {
+      W->idx = idx;
+      W->valid = 1u;
+      W->loc = loc;
+      W->hol = hol;
+      W->iters = iters;
+      W->done = 0u;
+      W->nrows = gridDim.x;
     }
   }
-  s_fin[tid] = v;
-  __syncthreads();
-  double lt = 0.0;
-  if (tid < J) {
-    for (uint32_t rr = 0; rr < R; ++rr) lt += s_fin[rr * J + tid];
-    lt *= s_eb[tid];  // the b[k,t] factored out of the accumulation
-  }
-  if (tid == 0) ctl->ticket = 0u;
-  if (p.tail == 1u) {
-    if (tid < J) ctl->lt[tid] = lt;
-    return;
-  }
-  epilogue_block<FIRST>(p, ctl, cur, loc, hol, lt, (tid < J) ? s_eb[tid] : 0.0, s_lam, s_diff);
 }
 
-// tail == 2: the partial rows of the preceding ts_pass launch (grid G) are added up in
-// the same fixed order by one workgroup after the kernel boundary; then either the
-// epilogue (single GPU) or ctl->lt for the all-reduce (to_lt).
-template <bool FIRST>
-__global__ __launch_bounds__(256) void ts_finish(DevParams p, uint32_t G, uint32_t to_lt) {
+#ifdef TSAMD_MAIN_TU  // K-independent kernels: compiled into tsamd.hip only
+// End of a schedule: complete the pending pass so that lambda/eb in the global arrays are
+// final (whole SNPs only are ever enqueued, so the pending pass is the SNP's last).
+__global__ __launch_bounds__(256) void ts_flush(DevParams p, uint32_t par) {
   __shared__ double s_fin[256];
   __shared__ double s_lam[2 * TSAMD_MAX_K];
+  __shared__ double s_eb[2 * TSAMD_MAX_K];
   __shared__ double s_diff[2 * TSAMD_MAX_K];
+  __shared__ uint32_t s_flag;
   Ctl *ctl = p.ctl;
+  const State *S = &ctl->st[par ^ 1u];
+  State *W = &ctl->st[par];
+  const uint32_t J = 2 * p.K;
+  if (S->valid != 0u && S->done == 0u) {
+    const double *rowsR = p.rows_from_lt ? ctl->lt_sum[par ^ 1u] : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
+    const uint32_t nrowsR = p.rows_from_lt ? 1u : S->nrows;
+    finish_pending<256>(p, S, rowsR, nrowsR, J, s_fin, s_lam, s_eb, s_diff, &s_flag);
+    publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
+  } else {
+    carry_state(S, W, J);
+  }
+}
+
+// Start of a schedule of n entries.  drop_pending: forget the pending gamma step
+// (tsamd_clear_pending).  n == 0xffffffff keeps the current schedule length.
+__global__ void ts_begin(Ctl *ctl, uint32_t n, uint32_t par, uint32_t J, uint32_t drop_pending) {
+  const State *S = &ctl->st[par ^ 1u];
+  State *W = &ctl->st[par];
+  carry_state(S, W, J);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (n != 0xffffffffu) {
+      ctl->sched_len = n;
+      W->idx = 0xffffffffu;
+    }
+    if (drop_pending) W->valid = 0u;
+  }
+}
+
+// Sharded: fixed-order sum of the partial rows the pass of this parity wrote -> ctl->lt
+__global__ __launch_bounds__(256) void ts_reduce_rows(DevParams p, uint32_t par) {
+  __shared__ double s_fin[256];
+  Ctl *ctl = p.ctl;
+  const State *W = &ctl->st[par];
   const uint32_t tid = threadIdx.x, J = 2 * p.K;
-  const uint32_t cur = ctl->cursor;
-  const uint32_t idx = FIRST ? cur : cur - 1u;
-  if (idx >= ctl->sched_len) return;
-  if (!FIRST && ctl->done) return;
-  const uint32_t ent = p.sched[idx];
-  const uint32_t loc = ent & 0x7fffffffu, hol = ent >> 31;
+  const uint32_t nrows = (W->valid != 0u && W->done == 0u) ? W->nrows : 0u;
+  const double *rows = p.partials + (size_t)par * kMaxGrid * J;
   const uint32_t R = 256u / J;
   const uint32_t j = tid % J, r = tid / J;
   double v = 0.0;
-  if (r < R)
-    for (uint32_t g0 = r; g0 < G; g0 += 8u * R) {
+  if (r < R && nrows > 0u) {
+    for (uint32_t g0 = r; g0 < nrows; g0 += 8u * R) {
       double t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = p.partials[(size_t)min(g0 + (uint32_t)u * R, G - 1u) * J + j];
+      for (int u = 0; u < 8; ++u) t[u] = rows[(size_t)min(g0 + (uint32_t)u * R, nrows - 1u) * J + j];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v += (g0 + (uint32_t)u * R < G) ? t[u] : 0.0;
+      for (int u = 0; u < 8; ++u) v += (g0 + (uint32_t)u * R < nrows) ? t[u] : 0.0;
     }
+  }
   s_fin[tid] = v;
   __syncthreads();
-  const double ebj = (tid < J) ? p.eb[(size_t)loc * J + tid] : 0.0;
-  double lt = 0.0;
   if (tid < J) {
+    double lt = 0.0;
     for (uint32_t rr = 0; rr < R; ++rr) lt += s_fin[rr * J + tid];
-    lt *= ebj;
+    ctl->lt[par][tid] = lt;
   }
-  if (to_lt) {
-    if (tid < J) ctl->lt[tid] = lt;
-    return;
-  }
-  epilogue_block<FIRST>(p, ctl, cur, loc, hol, lt, ebj, s_lam, s_diff);
 }
 
-// multi-GPU: epilogue after the RCCL all-reduce of ctl->lt into ctl->lt_sum
-template <bool FIRST>
-__global__ __launch_bounds__(64) void ts_epilogue(DevParams p) {
-  __shared__ double s_lam[2 * TSAMD_MAX_K];
-  __shared__ double s_diff[2 * TSAMD_MAX_K];
-  Ctl *ctl = p.ctl;
-  const uint32_t tid = threadIdx.x, J = 2 * p.K;
-  const uint32_t cur = ctl->cursor;
-  const uint32_t idx = FIRST ? cur : cur - 1u;
-  if (idx >= ctl->sched_len) return;
-  if (!FIRST && ctl->done) return;
-  const uint32_t ent = p.sched[idx];
-  const uint32_t loc = ent & 0x7fffffffu, hol = ent >> 31;
-  const double lt = (tid < J) ? ctl->lt_sum[tid] : 0.0;
-  const double ebj = (tid < J) ? p.eb[(size_t)loc * J + tid] : 0.0;
-  epilogue_block<FIRST>(p, ctl, cur, loc, hol, lt, ebj, s_lam, s_diff);
-}
+#endif  // TSAMD_MAIN_TU
 
 template <int KT>
 __global__ __launch_bounds__(kBlock) void ts_refresh_w(DevParams p) {
@@ -461,6 +551,7 @@ __global__ __launch_bounds__(kBlock) void ts_refresh_w(DevParams p) {
 // Host-side launcher of the K-specialised kernels; one translation unit per K
 // (tsamd_inst.hip compiled with -DTSAMD_K=<k>) defines tsamd::launch_k<k>.
 enum LaunchWhich { kLaunchPass = 0, kLaunchFirst = 1, kLaunchRefresh = 2 };
-using LaunchFn = void (*)(int which, uint32_t grid, uint32_t block, hipStream_t stream, const DevParams &p);
+using LaunchFn = void (*)(int which, uint32_t grid, uint32_t block, hipStream_t stream, const DevParams &p,
+                          uint32_t par);
 
 }  // namespace tsamd

@@ -11,7 +11,7 @@ pl = pack_bed(y); g = init_gamma(n, k, 56)
 locs = np.random.default_rng(4).integers(0, l, size=20).astype(np.uint32)
 orc = op.Oracle(n, l, k); orc.load_bed_payload(pl); orc.set_gamma(g)
 for loc in locs: orc.snp_update(int(loc))
-for name, flags in (("fused", 0), ("split", ts.FLAG_SPLIT_EPILOGUE), ("split-nograph", ts.FLAG_SPLIT_EPILOGUE | ts.FLAG_NO_GRAPH), ("fused-nograph", ts.FLAG_NO_GRAPH), ("finish", ts.FLAG_FINISH_KERNEL), ("finish+split", ts.FLAG_FINISH_KERNEL|ts.FLAG_SPLIT_EPILOGUE)):
+for name, flags in (("fused", 0), ("split", ts.FLAG_SPLIT_EPILOGUE), ("split-nograph", ts.FLAG_SPLIT_EPILOGUE | ts.FLAG_NO_GRAPH), ("fused-nograph", ts.FLAG_NO_GRAPH)):
     with ts.Engine(n, l, k, flags=flags) as e:
         e.upload_bed(pl); e.set_gamma(g)
         e.run_schedule(locs); e.synchronize()
