@@ -1,0 +1,742 @@
+// terastructure (MI355X host) -- command-line front end over libtsamd.
+//
+// Keeps the reference's command-line surface and on-disk outputs so that
+// data/run.sh works with only the binary path changed:
+//   flags                src/main.cc:84-187   (dead flags accepted and ignored)
+//   run directory, param.txt, network.dat symlink   src/env.hh:251-311
+//   validation sample    src/snpsamplinge.cc:196-224
+//   init_gamma           src/snpsamplinge.cc:226-237
+//   infer loop, reports  src/snpsamplinge.cc:417-459
+//   held-out likelihood, stop rule   src/snpsamplinge.cc:461-544
+//   gamma.txt / theta.txt / beta.txt src/snpsamplinge.cc:546-587, :761-798
+//   -compute-beta        src/snpsamplinge.cc:74-95, :368-413, :800-862
+// The SVI inner loop itself (optimize_lambda + deferred gamma step) runs on the GPU
+// behind include/tsamd.h.  There is no CPU path.  `-bfile <prefix>` is accepted as an
+// alias of `-file <prefix>.bed`.
+#include <errno.h>
+#include <math.h>
+#include <signal.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "tsamd.h"
+
+namespace {
+
+// ---- GSL-compatible random numbers (gsl_rng_mt19937 / gsl_rng_uniform_int /
+// gsl_ran_gamma; the unit normal uses the polar Box-Muller method) -----
+struct Mt19937 {
+  uint32_t mt[624];
+  int mti;
+  explicit Mt19937(unsigned long seed = 0) { set(seed); }
+  void set(unsigned long s) {
+    if (s == 0) s = 4357;  // gsl mt_set
+    mt[0] = (uint32_t)(s & 0xffffffffUL);
+    for (int i = 1; i < 624; ++i) mt[i] = (uint32_t)(1812433253UL * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (unsigned long)i);
+    mti = 624;
+  }
+  uint32_t get() {
+    if (mti >= 624) {
+      for (int kk = 0; kk < 624; ++kk) {
+        const uint32_t y = (mt[kk] & 0x80000000U) | (mt[(kk + 1) % 624] & 0x7fffffffU);
+        mt[kk] = mt[(kk + 397) % 624] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+      }
+      mti = 0;
+    }
+    uint32_t k = mt[mti++];
+    k ^= (k >> 11);
+    k ^= (k << 7) & 0x9d2c5680U;
+    k ^= (k << 15) & 0xefc60000U;
+    k ^= (k >> 18);
+    return k;
+  }
+  uint32_t uniform_int(uint32_t n) {
+    const uint32_t scale = 0xffffffffU / n;
+    uint32_t k;
+    do k = get() / scale;
+    while (k >= n);
+    return k;
+  }
+  double uniform_pos() {
+    double x;
+    do x = get() / 4294967296.0;
+    while (x == 0);
+    return x;
+  }
+  double gaussian() {
+    double x, y, r2;
+    do {
+      x = -1 + 2 * uniform_pos();
+      y = -1 + 2 * uniform_pos();
+      r2 = x * x + y * y;
+    } while (r2 > 1.0 || r2 == 0);
+    return y * sqrt(-2.0 * log(r2) / r2);
+  }
+  double gamma(double a, double b) {  // Marsaglia-Tsang
+    if (a < 1) {
+      const double u = uniform_pos();
+      return gamma(1.0 + a, b) * pow(u, 1.0 / a);
+    }
+    const double d = a - 1.0 / 3.0, c = (1.0 / 3.0) / sqrt(d);
+    double x, v, u;
+    while (true) {
+      do {
+        x = gaussian();
+        v = 1.0 + c * x;
+      } while (v <= 0);
+      v = v * v * v;
+      u = uniform_pos();
+      if (u < 1 - 0.0331 * x * x * x * x) break;
+      if (log(u) < 0.5 * x * x + d * (1 - v + log(v))) break;
+    }
+    return b * d * v;
+  }
+};
+
+volatile sig_atomic_t g_terminate = 0;
+void term_handler(int) {
+  printf("Got termination signal. Saving model state and quitting.\n");
+  fflush(stdout);
+  g_terminate = 1;
+}
+
+struct Options {
+  std::string datfname = "network.dat", label, eta_type = "default", idfile, locations_file;
+  uint32_t n = 0, k = 0, l = 0, rfreq = 10000, nthreads = 6;
+  bool rfreq_set = false, force = false, file_suffix = false, save_beta = false, adagrad = false;
+  bool use_test_set = false, compute_beta = false, logl = false, loadcmp = false;
+  double seed = 0, stop_threshold = 1e-5;
+  int device = 0;
+  uint32_t max_iter = 0;  // extension: stop after this many iterations (0 = reference behaviour)
+};
+
+struct Run {
+  Options o;
+  std::string prefix;  // run directory
+  FILE *plog = nullptr, *logf = nullptr, *vf = nullptr;
+  tsamd_ctx *ctx = nullptr;
+  time_t start_time = time(nullptr);
+  uint32_t iter = 0;
+  std::map<uint32_t, std::vector<uint32_t>> validation;  // loc -> ascending individuals
+  // stop rule state (src/snpsamplinge.cc:26-31)
+  double prev_h = -2147483647, max_h = -2147483647;
+  uint32_t nh = 0;
+  std::string bed_path;
+  uint64_t bytes_per_snp = 0;
+
+  std::string file_str(const std::string &f) const { return prefix + f; }
+  uint32_t duration() const { return (uint32_t)(time(nullptr) - start_time); }
+  void lerr(const char *fmt, ...) {
+    if (!logf) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(logf, fmt, ap);
+    va_end(ap);
+    fputc('\n', logf);
+    fflush(logf);
+  }
+  void plog_u(const char *k, unsigned long v) { fprintf(plog, "%s: %lu\n", k, v), fflush(plog); }
+  void plog_d(const char *k, double v) { fprintf(plog, "%s: %.9f\n", k, v), fflush(plog); }
+  void plog_b(const char *k, bool v) { fprintf(plog, "%s: %s\n", k, v ? "True" : "False"), fflush(plog); }
+};
+
+[[noreturn]] void die(Run &r, const char *what) {
+  fprintf(stderr, "error: %s: %s\n", what, tsamd_last_error(r.ctx));
+  r.lerr("error: %s: %s", what, tsamd_last_error(r.ctx));
+  exit(-1);
+}
+#define TS(r, call)               \
+  do {                            \
+    if ((call) != 0) die(r, #call); \
+  } while (0)
+
+void usage() {
+  fprintf(stdout,
+          "Population inference software for SNP data (MI355X build).\n"
+          "terastructure [OPTIONS]\n"
+          "\t-help\t\tusage\n"
+          "\t-file <name>\t PLINK .bed file (SNP-major); .bim/.fam are found next to it\n"
+          "\t-bfile <prefix>\t same as -file <prefix>.bed\n"
+          "\t-n <N>\t\t number of individuals\n"
+          "\t-l <L>\t\t number of locations\n"
+          "\t-k <K>\t\t number of populations\n"
+          "\t-label\t\t descriptive tag for the output directory\n"
+          "\t-force\t\t overwrite existing output directory\n"
+          "\t-rfreq <val>\t checks for convergence and logs output every <val> iterations\n"
+          "\t-seed <val>\t random seed\n"
+          "\t-compute-beta\t compute allele frequencies given ./gamma.txt\n"
+          "\t-device <id>\t HIP device ordinal (default 0)\n");
+  fflush(stdout);
+}
+
+int count_lines(const std::string &path) {
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) return -1;
+  int n = 0;
+  char buf[20480];
+  while (fgets(buf, sizeof buf, f) != nullptr) n++;
+  fclose(f);
+  return n;
+}
+
+// Env::Env directory naming + param.txt (src/env.hh:251-311)
+void setup_run_dir(Run &r) {
+  const Options &o = r.o;
+  std::ostringstream sa;
+  sa << "n" << o.n << "-" << "k" << o.k << "-" << "l" << o.l;
+  if (o.label != "")
+    sa << "-" << o.label;
+  else if (o.datfname.length() > 3) {
+    std::string q = o.datfname.substr(0, 2);
+    if (q == "..") q = "xx";
+    sa << "-" << q;
+  }
+  if (o.seed != 0) sa << "-" << "seed" << o.seed;
+  r.prefix = sa.str();
+  fprintf(stdout, "+ Creating directory %s\n", r.prefix.c_str());
+  struct stat st;
+  if (stat(r.prefix.c_str(), &st) != 0) {
+    if (errno != ENOENT || mkdir(r.prefix.c_str(), S_IRWXU | S_IRWXG | S_IROTH | S_IXOTH) != 0) {
+      fprintf(stderr, "Warning: could not create dir %s\n", r.prefix.c_str());
+      exit(-1);
+    }
+  } else if (!o.force) {
+    fprintf(stderr, "Error: dir %s already exists\n", r.prefix.c_str());
+    exit(-1);
+  }
+  r.logf = fopen(r.file_str("/infer.log").c_str(), "w");
+  r.plog = fopen(r.file_str("/param.txt").c_str(), "w");
+  if (!r.plog || !r.logf) {
+    printf("cannot open param file:%s\n", strerror(errno));
+    exit(-1);
+  }
+  const uint32_t blocks = o.n > 10000 ? 100 : 10;
+  r.plog_u("n", o.n);
+  r.plog_u("k", o.k);
+  r.plog_u("t", 2);
+  r.plog_u("l", o.l);
+  r.plog_u("nthreads", o.nthreads);
+  r.plog_d("tau0", 1);
+  r.plog_d("nodetau0", 1);
+  r.plog_d("kappa", 0.5);
+  r.plog_d("nodekappa", 0.5);
+  r.plog_d("alpha", 1.0 / o.k);
+  r.plog_d("heldout_indiv_ratio", 0.001);
+  r.plog_d("validation_ratio", 0.005);
+  r.plog_u("online_iterations", 10);
+  r.plog_d("GSL seed", o.seed);
+  r.plog_b("file suffix", o.file_suffix);
+  r.plog_b("save beta", o.save_beta);
+  r.plog_b("adagrad", o.adagrad);
+  r.plog_u("indiv sample size", o.n / blocks);
+  r.plog_u("blocks", blocks);
+  r.plog_b("compute_beta", o.compute_beta);
+  r.plog_d("stop_threshold", o.stop_threshold);
+  const std::string nd = r.file_str("/network.dat");
+  unlink(nd.c_str());
+  if (symlink(o.datfname.c_str(), nd.c_str()) < 0) fprintf(stderr, "warning: cannot symlink %s\n", nd.c_str());
+  fprintf(stderr, "+ done initializing env\n");
+}
+
+// SNP::read_bed (src/snp.cc:95-253): line counts must match -l / -n, magic 6c 1b 01,
+// then the SNP-major payload goes to HBM as is.
+void read_bed(Run &r) {
+  const Options &o = r.o;
+  const std::string prefix = o.datfname.substr(0, o.datfname.length() - 4);
+  const int l = count_lines(prefix + ".bim");
+  if (l < 0) {
+    fprintf(stderr, "cannot open file %s.bim:%s\n", prefix.c_str(), strerror(errno));
+    exit(-1);
+  }
+  printf("+ bim file tells us %d SNPs\n", l);
+  if ((uint32_t)l != o.l) {
+    fprintf(stderr, "-l input doesn't match SNPs in bim file\n");
+    exit(-1);
+  }
+  const int n = count_lines(prefix + ".fam");
+  if (n < 0) {
+    fprintf(stderr, "cannot open file %s.fam:%s\n", prefix.c_str(), strerror(errno));
+    exit(-1);
+  }
+  printf("+ fam file tells us %d individuals\n", n);
+  if ((uint32_t)n != o.n) {
+    fprintf(stderr, "-n input doesn't match individuals in fam file\n");
+    exit(-1);
+  }
+  r.bed_path = prefix + ".bed";
+  r.bytes_per_snp = ((uint64_t)o.n + 3) / 4;
+  FILE *f = fopen(r.bed_path.c_str(), "rb");
+  if (!f) {
+    fprintf(stderr, "cannot open file %s:%s\n", r.bed_path.c_str(), strerror(errno));
+    exit(-1);
+  }
+  unsigned char magic[3];
+  if (fread(magic, 1, 3, f) != 3 || magic[0] != 108 || magic[1] != 27) {
+    fprintf(stderr, "%s magic number incorrect\n", r.bed_path.c_str());
+    exit(-1);
+  }
+  if (magic[2] == 0) {
+    fprintf(stderr, "individual major mode not supported yet!\n");
+    exit(-1);
+  } else if (magic[2] != 1) {
+    fprintf(stderr, "mode problem in %s\n", r.bed_path.c_str());
+    exit(-1);
+  }
+  // per-byte counts of each 2-bit code, tail bits of the last byte excluded
+  uint64_t cnt[4] = {0, 0, 0, 0};
+  const size_t batch = std::max<size_t>(1, (size_t)(64u << 20) / r.bytes_per_snp);
+  std::vector<uint8_t> buf(batch * r.bytes_per_snp);
+  uint32_t loc = 0;
+  while (loc < o.l) {
+    const size_t want = std::min<size_t>(batch, o.l - loc);
+    const size_t got = fread(buf.data(), r.bytes_per_snp, want, f);
+    if (got == 0) break;
+    for (size_t j = 0; j < got; ++j) {
+      const uint8_t *col = buf.data() + j * r.bytes_per_snp;
+      for (uint32_t i = 0; i < o.n; ++i) cnt[(col[i >> 2] >> (2 * (i & 3))) & 3]++;
+    }
+    TS(r, tsamd_upload_bed(r.ctx, buf.data(), r.bytes_per_snp, loc, (uint32_t)got));
+    loc += (uint32_t)got;
+    if (loc % 20000 < got) {
+      printf("\r%d locations read", loc);
+      fflush(stdout);
+    }
+  }
+  fclose(f);
+  if (loc != o.l) {
+    fprintf(stderr, "%s is truncated: %u of %u locations\n", r.bed_path.c_str(), loc, o.l);
+    exit(-1);
+  }
+  r.plog_u("missing snps", cnt[1]);
+  r.plog_u("0s snps", cnt[3]);  // labels swapped like the reference (src/snp.cc:207-216, :245-247)
+  r.plog_u("1s snps", cnt[2]);
+  r.plog_u("2s snps", cnt[0]);
+}
+
+std::vector<uint8_t> read_column(Run &r, uint32_t loc) {
+  std::vector<uint8_t> col(r.bytes_per_snp);
+  FILE *f = fopen(r.bed_path.c_str(), "rb");
+  if (!f || fseeko(f, 3 + (off_t)loc * (off_t)r.bytes_per_snp, SEEK_SET) != 0 ||
+      fread(col.data(), 1, col.size(), f) != col.size()) {
+    fprintf(stderr, "cannot read location %u of %s\n", loc, r.bed_path.c_str());
+    exit(-1);
+  }
+  fclose(f);
+  return col;
+}
+
+// set_validation_sample (src/snpsamplinge.cc:196-224): kv_ok = not held out yet, not missing
+void set_validation_sample(Run &r, Mt19937 &rng) {
+  const uint32_t n = r.o.n, l = r.o.l;
+  const uint32_t per_loc_h = n < 2000 ? (n / 10) : (n / 100);
+  const double validation_ratio = 0.005;
+  const uint32_t nlocs = (uint32_t)(l * validation_ratio);
+  std::map<uint32_t, bool> lm;
+  do {
+    const uint32_t loc = rng.uniform_int(l);
+    if (lm.find(loc) != lm.end()) continue;
+    lm[loc] = true;
+    const std::vector<uint8_t> col = read_column(r, loc);
+    std::vector<bool> held(n, false);
+    std::vector<uint32_t> &v = r.validation[loc];
+    uint32_t c = 0;
+    while (c < per_loc_h) {
+      const uint32_t indiv = rng.uniform_int(n);
+      const uint32_t code = (col[indiv >> 2] >> (2 * (indiv & 3))) & 3;
+      if (!held[indiv] && code != 1) {
+        held[indiv] = true;
+        v.push_back(indiv);
+        c++;
+      }
+    }
+    std::sort(v.begin(), v.end());
+    if (v.empty())
+      r.validation.erase(loc);
+    else
+      TS(r, tsamd_set_heldout(r.ctx, loc, v.data(), (uint32_t)v.size()));
+  } while (lm.size() < nlocs);
+  r.plog_u("validation snps per location", per_loc_h);
+  r.plog_u("validation locations", nlocs);
+  r.plog_u("total validation snps", (unsigned long)per_loc_h * nlocs);
+  size_t total = 0;
+  for (auto &kv : r.validation) total += kv.second.size();
+  r.plog_u("(VAL1) total validation snps (check)", total);
+  r.plog_d("test ratio", 0.005);
+  r.plog_d("validation ratio", 0.005);
+}
+
+std::string add_iter_suffix(const Run &r, const char *c) {
+  std::ostringstream sa;
+  if (r.o.file_suffix)
+    sa << c << "_" << r.iter << ".txt";
+  else
+    sa << c << ".txt";
+  return r.file_str(sa.str());
+}
+
+// save_gamma (src/snpsamplinge.cc:546-576)
+void save_model(Run &r) {
+  const size_t n = r.o.n, k = r.o.k;
+  std::vector<double> g(n * k), t(n * k);
+  TS(r, tsamd_get_gamma(r.ctx, g.data()));
+  TS(r, tsamd_get_theta(r.ctx, t.data()));
+  FILE *f = fopen(add_iter_suffix(r, "/gamma").c_str(), "w");
+  FILE *h = fopen(add_iter_suffix(r, "/theta").c_str(), "w");
+  if (!f || !h) {
+    r.lerr("cannot open gamma/theta file:%s\n", strerror(errno));
+    exit(-1);
+  }
+  for (size_t i = 0; i < n; ++i) {
+    for (size_t j = 0; j < k; ++j) {
+      fprintf(f, "%.8f\t", g[i * k + j]);
+      fprintf(h, "%.8f\t", t[i * k + j]);
+    }
+    fprintf(f, "\n");
+    fprintf(h, "\n");
+  }
+  fclose(f);
+  fclose(h);
+}
+
+// compute_likelihood(first, validation = true) (src/snpsamplinge.cc:461-544);
+// returns true when the stop rule fires
+bool compute_likelihood(Run &r, bool first) {
+  uint32_t k = 0;
+  double s = .0;
+  size_t sz = 0;
+  for (auto &kv : r.validation) {
+    const uint32_t loc = kv.first;
+    printf("\rdone:%.2f%%", ((double)sz / r.validation.size()) * 100);
+    if (!first) {  // snp_likelihood: optimize_lambda(loc) in hol mode, then _iter++
+      TS(r, tsamd_snp_update(r.ctx, loc, 1, nullptr));
+      r.iter++;
+    }
+    double u = 0;
+    uint32_t c = 0;
+    TS(r, tsamd_heldout_loglik(r.ctx, loc, &u, &c));
+    s += u;
+    k += c;
+    sz++;
+  }
+  fprintf(r.vf, "%d\t%d\t%.9f\t%d\t%f\n", r.iter, r.duration(), (s / k), k, exp(s / k));
+  fflush(r.vf);
+  const double a = s / k;
+  bool stop = false;
+  if (r.iter > 2000) {
+    if (a > r.prev_h && r.prev_h != 0 && fabs((a - r.prev_h) / r.prev_h) < r.o.stop_threshold)
+      stop = true;
+    else if (a < r.prev_h)
+      r.nh++;
+    else if (a > r.prev_h)
+      r.nh = 0;
+    if (a > r.max_h) r.max_h = a;
+    if (r.nh > 3) stop = true;
+  }
+  r.prev_h = a;
+  return stop;
+}
+
+void save_beta(Run &r, const std::vector<uint32_t> *locs) {
+  const size_t k = r.o.k;
+  FILE *f = fopen(add_iter_suffix(r, "/beta").c_str(), "w");
+  if (!f) {
+    r.lerr("cannot open beta or lambda file:%s\n", strerror(errno));
+    exit(-1);
+  }
+  const uint32_t chunk = 1u << 16;
+  std::vector<double> eb((size_t)chunk * k);
+  if (!locs) {
+    for (uint32_t l0 = 0; l0 < r.o.l; l0 += chunk) {
+      const uint32_t nl = std::min(chunk, r.o.l - l0);
+      TS(r, tsamd_get_ebeta(r.ctx, l0, nl, eb.data()));
+      for (uint32_t j = 0; j < nl; ++j) {
+        fprintf(f, "%d\t", l0 + j);
+        for (size_t q = 0; q < k; ++q) fprintf(f, "%.8f\t", eb[(size_t)j * k + q]);
+        fprintf(f, "\n");
+      }
+    }
+  } else {
+    for (uint32_t loc : *locs) {
+      TS(r, tsamd_get_ebeta(r.ctx, loc, 1, eb.data()));
+      fprintf(f, "%d\t", loc);
+      for (size_t q = 0; q < k; ++q) fprintf(f, "%.8f\t", eb[q]);
+      fprintf(f, "\n");
+    }
+  }
+  fclose(f);
+}
+
+// load_gamma (src/snpsamplinge.cc:800-862): ./gamma.txt of the CURRENT directory
+void load_gamma(Run &r) {
+  const size_t n = r.o.n, k = r.o.k;
+  FILE *gf = fopen("gamma.txt", "r");
+  if (!gf) {
+    r.lerr("cannot open gamma file:%s\n", strerror(errno));
+    fprintf(stderr, "cannot open gamma file:%s\n", strerror(errno));
+    exit(-1);
+  }
+  std::vector<double> g(n * k, 1.0);
+  const int sz = 128 * (int)k;
+  std::vector<char> line(sz);
+  size_t row = 0;
+  while (row < n && fgets(line.data(), sz, gf) != nullptr) {
+    char *p = line.data();
+    for (size_t j = 0; j < k; ++j) {
+      char *q = nullptr;
+      const double d = strtod(p, &q);
+      if (p == q) {
+        fprintf(stderr, "error parsing gamma file\n");
+        exit(-1);
+      }
+      g[row * k + j] = d;
+      p = q;
+    }
+    row++;
+  }
+  fclose(gf);
+  if (row != n) {
+    fprintf(stderr, "gamma.txt has %zu rows, expected %zu\n", row, n);
+    exit(-1);
+  }
+  TS(r, tsamd_set_gamma(r.ctx, g.data()));
+  FILE *f = fopen(r.file_str("/gammasave.txt").c_str(), "w");
+  if (f) {
+    for (size_t i = 0; i < n; ++i) {
+      fprintf(f, "%zu\t%s\t", i, "unknown");
+      double mx = .0;
+      size_t mk = 0;
+      for (size_t j = 0; j < k; ++j) {
+        fprintf(f, "%.8f\t", g[i * k + j]);
+        if (g[i * k + j] > mx) mx = g[i * k + j], mk = j;
+      }
+      fprintf(f, "%zu\n", mk);
+    }
+    fclose(f);
+  }
+}
+
+void run_batch(Run &r, const std::vector<uint32_t> &locs) {
+  TS(r, tsamd_run_schedule(r.ctx, locs.data(), (uint32_t)locs.size(), 0));
+  TS(r, tsamd_synchronize(r.ctx));
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  signal(SIGTERM, term_handler);
+  Run r;
+  Options &o = r.o;
+  if (argc == 1) {
+    usage();
+    exit(-1);
+  }
+  for (int i = 1; i < argc; ++i) {
+    auto need = [&](const char *flag) -> const char * {
+      if (i + 1 > argc - 1) {
+        fprintf(stderr, "+ insufficient arguments for %s!\n", flag);
+        exit(-1);
+      }
+      return argv[++i];
+    };
+    const char *a = argv[i];
+    if (!strcmp(a, "-help")) {
+      usage();
+      exit(0);
+    } else if (!strcmp(a, "-force")) {
+      fprintf(stdout, "+ overwrite option set\n");
+      o.force = true;
+    } else if (!strcmp(a, "-online") || !strcmp(a, "-E") || !strcmp(a, "-stochastic")) {
+      fprintf(stdout, "+ stochastic option set\n");
+    } else if (!strcmp(a, "-file") || !strcmp(a, "-bed")) {
+      o.datfname = need(a);
+      fprintf(stdout, "+ using file %s\n", o.datfname.c_str());
+    } else if (!strcmp(a, "-bfile")) {
+      o.datfname = std::string(need(a)) + ".bed";
+      fprintf(stdout, "+ using file %s\n", o.datfname.c_str());
+    } else if (!strcmp(a, "-batch")) {
+      fprintf(stdout, "batch option currently not available");
+      exit(0);
+    } else if (!strcmp(a, "-n")) {
+      o.n = atoi(need(a));
+      fprintf(stdout, "+ n = %d\n", o.n);
+    } else if (!strcmp(a, "-k")) {
+      o.k = atoi(need(a));
+      fprintf(stdout, "+ K = %d\n", o.k);
+    } else if (!strcmp(a, "-l")) {
+      o.l = atoi(need(a));
+      fprintf(stdout, "+ L = %d\n", o.l);
+    } else if (!strcmp(a, "-label")) {
+      o.label = need(a);
+    } else if (!strcmp(a, "-eta-type")) {
+      o.eta_type = need(a);
+    } else if (!strcmp(a, "-rfreq")) {
+      o.rfreq = atoi(need(a));
+      o.rfreq_set = true;
+      fprintf(stdout, "+ rfreq = %d\n", o.rfreq);
+    } else if (!strcmp(a, "-logl")) {
+      o.logl = true;
+    } else if (!strcmp(a, "-idfile")) {
+      o.idfile = need(a);  // labels are only echoed into gammasave.txt by the reference
+    } else if (!strcmp(a, "-loadcmp")) {
+      o.loadcmp = true;
+    } else if (!strcmp(a, "-seed")) {
+      o.seed = atof(need(a));
+      fprintf(stdout, "+ random seed set to %.5f\n", o.seed);
+    } else if (!strcmp(a, "-file-suffix")) {
+      o.file_suffix = true;
+    } else if (!strcmp(a, "-save-beta")) {
+      o.save_beta = true;
+    } else if (!strcmp(a, "-adagrad")) {
+      o.adagrad = true;
+    } else if (!strcmp(a, "-nthreads")) {
+      o.nthreads = atoi(need(a));  // accepted; the GPU replaces the worker threads
+    } else if (!strcmp(a, "-use-test-set")) {
+      o.use_test_set = true;  // broken in the reference (writes to an unopened FILE*); ignored
+    } else if (!strcmp(a, "-locations-file")) {
+      o.locations_file = need(a);
+    } else if (!strcmp(a, "-compute-beta")) {
+      o.compute_beta = true;
+    } else if (!strcmp(a, "-stop-threshold")) {
+      o.stop_threshold = atof(need(a));
+    } else if (!strcmp(a, "-device")) {
+      o.device = atoi(need(a));
+    } else if (!strcmp(a, "-max-iter")) {
+      o.max_iter = atoi(need(a));
+    } else {
+      fprintf(stdout, "error: unknown option %s\n", a);
+      exit(-1);
+    }
+  }
+  if (!o.rfreq_set) o.rfreq = 100000;
+  if (o.n == 0 || o.l == 0 || o.k == 0) {
+    fprintf(stderr, "error: -n, -l and -k are required\n");
+    exit(-1);
+  }
+  if (o.loadcmp) {
+    fprintf(stdout, "+ loadcmp option set: nothing to do\n");
+    return 0;
+  }
+
+  // the GPU context comes first so that a missing device fails before any output exists
+  tsamd_config cfg;
+  tsamd_default_config(&cfg, o.n, o.l, o.k);
+  cfg.device = o.device;
+  if (o.compute_beta) cfg.max_inner = 100;  // tightly optimize given the thetas (:75)
+  if (tsamd_create(&cfg, &r.ctx) != 0) {
+    fprintf(stderr, "error: tsamd_create: %s\n", tsamd_last_error(nullptr));
+    return -1;
+  }
+
+  setup_run_dir(r);
+  read_bed(r);
+  printf("+ initialization begin\n");
+  fflush(stdout);
+  r.plog_u("individuals n", o.n);
+  r.plog_u("locations l", o.l);
+  r.plog_u("populations k", o.k);
+
+  Mt19937 rng(0);  // gsl_rng_alloc: default seed 0 -> 4357
+  if (o.seed) rng.set((unsigned long)o.seed);
+  unlink(r.file_str("/likelihood-analysis.txt").c_str());
+  r.vf = fopen(r.file_str("/validation.txt").c_str(), "w");
+  if (!r.vf) {
+    printf("cannot open heldout file:%s\n", strerror(errno));
+    exit(-1);
+  }
+
+  if (o.compute_beta) {
+    set_validation_sample(r, rng);
+    r.lerr("done starting threads");
+    load_gamma(r);
+    r.lerr("done estimating all theta");
+    std::vector<uint32_t> locs;
+    if (o.locations_file == "") {
+      locs.resize(o.l);
+      for (uint32_t i = 0; i < o.l; ++i) locs[i] = i;
+    } else {
+      FILE *f = fopen(o.locations_file.c_str(), "r");
+      if (!f) {
+        fprintf(stderr, "cannot open %s\n", o.locations_file.c_str());
+        exit(-1);
+      }
+      char line[16384];
+      while (fgets(line, sizeof line, f) != nullptr) {
+        unsigned v;
+        if (sscanf(line, "%u", &v) == 1 && v < o.l) locs.push_back(v);
+      }
+      fclose(f);
+    }
+    // compute_all_lambda (:368-381): the same hot path per location, gamma steps included
+    const size_t chunk = 4096;
+    for (size_t i0 = 0; i0 < locs.size(); i0 += chunk) {
+      std::vector<uint32_t> part(locs.begin() + i0, locs.begin() + std::min(locs.size(), i0 + chunk));
+      run_batch(r, part);
+      r.iter += (uint32_t)part.size();
+      printf("\rloc = %d took %d secs", r.iter, r.duration());
+      fflush(stdout);
+    }
+    save_beta(r, o.locations_file == "" ? nullptr : &locs);
+    tsamd_destroy(r.ctx);
+    return 0;
+  }
+
+  set_validation_sample(r, rng);
+  {  // init_gamma (:226-237): n-major, k inner, Gamma(100 v, 0.01)
+    std::vector<double> g((size_t)o.n * o.k);
+    for (size_t i = 0; i < g.size(); ++i) {
+      const double v = (o.k < 100) ? 1.0 : (double)100.0 / o.k;
+      g[i] = rng.gamma(100 * v, 0.01);
+    }
+    TS(r, tsamd_set_gamma(r.ctx, g.data()));
+  }
+  printf("+ computing initial heldout likelihood\n");
+  compute_likelihood(r, true);
+  save_model(r);
+  printf("\n+ computing initial training likelihood\n+ done..\n+ initialization end\n");
+  fflush(stdout);
+
+  // infer() (:417-459).  Locations are drawn one per iteration from the same stream; they
+  // are data-independent, so a whole report period is enqueued at once.
+  while (true) {
+    uint32_t c = o.rfreq - (r.iter % o.rfreq);
+    c = std::min<uint32_t>(c, 4096);  // bounds the latency of a SIGTERM
+    if (o.max_iter && r.iter + c > o.max_iter) c = o.max_iter > r.iter ? o.max_iter - r.iter : 0;
+    std::vector<uint32_t> locs(c);
+    for (uint32_t i = 0; i < c; ++i) locs[i] = rng.uniform_int(o.l);
+    if (c) run_batch(r, locs);
+    r.iter += c;
+    printf("\riteration = %d took %d secs", r.iter, r.duration());
+    fflush(stdout);
+    if (c && r.iter % o.rfreq == 0) {
+      printf("iteration = %d took %d secs\n", r.iter, r.duration());
+      r.lerr("iteration = %d took %d secs\n", r.iter, r.duration());
+      r.lerr("computing heldout likelihood @ %d secs", r.duration());
+      if (compute_likelihood(r, false)) {
+        save_model(r);
+        break;
+      }
+      r.lerr("saving theta @ %d secs", r.duration());
+      save_model(r);
+      r.lerr("done @ %d secs", r.duration());
+    }
+    if (g_terminate || (o.max_iter && r.iter >= o.max_iter)) {
+      save_model(r);
+      break;
+    }
+  }
+  printf("\n");
+  tsamd_destroy(r.ctx);
+  return 0;
+}

@@ -1,0 +1,116 @@
+"""The C++ command-line host (host/terastructure) over libtsamd: the reference's
+data/run.sh, verbatim except for the binary path, against the oracle."""
+import ctypes as C
+import itertools
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_py as op
+from conftest import REF_DATA, ROOT
+
+HOST = os.path.join(ROOT, "host", "terastructure")
+
+
+@pytest.fixture(scope="module")
+def host_bin():
+    from terastructure_amd import build
+
+    build.build()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    return HOST
+
+
+def test_help_and_argument_errors(host_bin, tmp_path):
+    r = subprocess.run([host_bin, "-help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "-file <name>" in r.stdout and "-rfreq" in r.stdout
+    r = subprocess.run([host_bin, "-frobnicate"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode != 0 and "unknown option" in r.stdout
+    r = subprocess.run([host_bin, "-file", "x.bed", "-k", "3"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode != 0 and "-n, -l and -k are required" in r.stderr
+    assert os.listdir(tmp_path) == []
+
+
+def test_without_gpu_fails_before_writing(host_bin, tmp_path):
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("GPU present")
+    r = subprocess.run([host_bin, "-file", os.path.join(REF_DATA, "test.bed"), "-n", "200", "-l", "10000", "-k", "3"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode != 0 and "no CPU path" in r.stderr
+    assert os.listdir(tmp_path) == []
+
+
+def _read_matrix(path):
+    return np.array([[float(x) for x in line.split()] for line in open(path)])
+
+
+@pytest.mark.gpu
+def test_run_sh_end_to_end(host_bin, tmp_path):
+    data = tmp_path / "data"
+    data.mkdir()
+    for f in ("test.bed", "test.bim", "test.fam"):
+        shutil.copy(os.path.join(REF_DATA, f), data / f)
+    # data/run.sh line 1
+    cmd1 = [host_bin, "-file", "test.bed", "-n", "200", "-l", "10000", "-k", "3", "-stochastic",
+            "-nthreads", "1", "-rfreq", "1000", "-seed", "1234", "-label", "test"]
+    r = subprocess.run(cmd1, cwd=data, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = data / "n200-k3-l10000-test-seed1234"
+    for f in ("infer.log", "param.txt", "validation.txt", "gamma.txt", "theta.txt"):
+        assert (run / f).exists(), f
+    # symlink to the data file exactly as given on the command line (src/env.hh:309-311)
+    assert os.path.islink(run / "network.dat") and os.readlink(run / "network.dat") == "test.bed"
+    param = open(run / "param.txt").read()
+    assert "validation locations: 50" in param and "validation snps per location: 20" in param
+    assert "missing snps: 0" in param and "GSL seed: 1234.000000000" in param
+    # an existing directory without -force is refused (src/log.cc:113-116)
+    r2 = subprocess.run(cmd1, cwd=data, capture_output=True, text=True, timeout=60)
+    assert r2.returncode != 0 and "already exists" in r2.stderr
+
+    # the oracle on the same stream
+    orc = op.Oracle(200, 10000, 3)
+    orc.read_bed_file(os.path.join(REF_DATA, "test.bed"))
+    res = orc.run(seed=1234, reportfreq=1000)
+    val = [line.split("\t") for line in open(run / "validation.txt").read().splitlines()]
+    assert len(val) == len(res["lines"]) == 17
+    assert val[0][0] == "0" and val[0][2] == "-1.169339294" and val[0][3] == "1000"
+    assert val[1][0] == "1050" and val[1][2] == "-0.732008912"
+    assert val[-1][0] == "16050"
+    for got, (it, ll, cnt) in zip(val, res["lines"]):
+        assert int(got[0]) == it and int(got[3]) == cnt
+        assert abs(float(got[2]) - ll) < 1e-8
+    theta = _read_matrix(run / "theta.txt")
+    gamma = _read_matrix(run / "gamma.txt")
+    assert theta.shape == (200, 3)
+    assert np.max(np.abs(theta - orc.theta())) <= 1e-6          # stated tolerance
+    assert np.max(np.abs(gamma - orc.gamma()) / orc.gamma()) <= 1e-6
+    raw = open(run / "theta.txt").read()
+    assert raw.count("\n") == 200 and raw.split("\n")[0].endswith("\t")   # "%.8f\t" * K + "\n"
+
+    # data/run.sh lines 2-3: -compute-beta from inside the run directory
+    cmd2 = [host_bin, "-file", "../test.bed", "-n", "200", "-l", "10000", "-k", "3", "-stochastic",
+            "-nthreads", "1", "-compute-beta"]
+    r = subprocess.run(cmd2, cwd=run, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bdir = run / "n200-k3-l10000-xx"
+    beta = _read_matrix(bdir / "beta.txt")
+    assert beta.shape == (10000, 4) and np.array_equal(beta[:, 0], np.arange(10000))
+    assert (bdir / "gammasave.txt").exists()
+    # same sweep in the oracle: gamma re-read from the %.8f text, fresh default-seed validation sample
+    o2 = op.Oracle(200, 10000, 3)
+    o2.read_bed_file(os.path.join(REF_DATA, "test.bed"))
+    rng = op.gsl_mt19937(0)
+    op.lib().orc_set_validation_sample(o2.s, C.byref(rng))
+    o2.set_gamma(gamma)
+    o2.compute_all_lambda()
+    assert np.max(np.abs(beta[:, 1:] - o2.ebeta())) <= 1e-6
+    # and against the reference's ground truth (allele coding flipped)
+    truth_t = np.loadtxt(os.path.join(REF_DATA, "oracle_theta.txt"))
+    perm = min(itertools.permutations(range(3)), key=lambda p: np.mean((theta[:, list(p)] - truth_t) ** 2))
+    truth_b = np.loadtxt(os.path.join(REF_DATA, "oracle_beta.txt"))
+    assert np.sqrt(np.mean(((1 - beta[:, 1:][:, list(perm)]) - truth_b) ** 2)) <= 0.05
