@@ -44,6 +44,51 @@ def parse():
     return ap.parse_args()
 
 
+def choose_exchange(ts, dist, rank, world, local_rank, k):
+    """Per-pass exchange of the 2K lambda statistics: direct peer-to-peer stores over xGMI
+    when a small self-test reproduces the RCCL all-reduce result on this node, else RCCL.
+    TSAMD_EXCHANGE=rccl|p2p forces one."""
+    import torch
+
+    from terastructure_amd import dist as tdist
+
+    forced = os.environ.get("TSAMD_EXCHANGE", "auto").lower()
+    if forced in ("rccl", "p2p"):
+        return forced
+    n, l = 8192 * world, 8
+    rng = np.random.default_rng(7)
+    theta = rng.dirichlet(np.full(k, 0.2), size=n)
+    beta = rng.uniform(0.05, 0.95, size=(l, k))
+    gamma = rng.gamma(100.0, 0.01, size=(n, k))
+    locs = np.array([3, 1, 3, 7, 0, 5], dtype=np.uint32)
+    out = {}
+    ok = 1.0
+    for mode in ("rccl", "p2p"):
+        try:
+            with ts.Engine(n, l, k, device=local_rank, rank=rank, world=world) as e:
+                b, c = e.shard_begin, e.shard_count
+                e.synth_genotypes(theta[b:b + c], beta, seed=11)
+                e.set_gamma(gamma[b:b + c])
+                (tdist.bootstrap_p2p if mode == "p2p" else tdist.bootstrap_comm)(e, dist)
+                e.run_schedule(locs)
+                e.synchronize()
+                out[mode] = (e.get_lambda(), e.get_gamma())
+                dist.barrier()
+        except Exception as exc:  # noqa: BLE001 -- any failure means: do not use this mode
+            if rank == 0:
+                print(f"[bench] exchange self-test, mode {mode}: {exc}", file=sys.stderr, flush=True)
+            out[mode] = None
+            if mode == "p2p":
+                ok = 0.0
+    if ok and out["rccl"] is not None:
+        for a, b_ in zip(out["rccl"], out["p2p"]):
+            if not np.allclose(a, b_, rtol=1e-10, atol=0):
+                ok = 0.0
+    t = torch.tensor([ok], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return "p2p" if t.item() > 0 else "rccl"
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,11 +127,17 @@ def main():
         l = int(t.item())
 
     t_setup = time.time()
+    exchange = "none"
+    if world > 1:
+        exchange = choose_exchange(ts, dist, rank, world, local_rank, k)
     eng = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
     if world > 1:
-        uid = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(uid[0])
+        from terastructure_amd import dist as tdist
+
+        if exchange == "p2p":
+            tdist.bootstrap_p2p(eng, dist)
+        else:
+            tdist.bootstrap_comm(eng, dist)
 
     # synthetic PSD data: theta ~ Dir(0.2), beta ~ U(0.05, 0.95), y ~ Bin(2, theta.beta)
     rng = np.random.default_rng(args.seed)
@@ -197,7 +248,7 @@ def main():
             "config": {"workload": f"synthetic PSD N={n} individuals x L={l} SNPs, K={k}, 2-bit genotypes "
                                    f"HBM-resident, individuals sharded over {world} GPU(s)",
                        "n": n, "l": l, "k": k, "l_requested": args.l,
-                       "parallelism": f"individual-shard x{world}"},
+                       "parallelism": f"individual-shard x{world}", "exchange": exchange},
             "mean_inner_passes": round(mean_passes, 3),
             "nk_pass_per_s": round(value * mean_passes * n * k, 1),
             "update_algorithmic_bytes": alg_update,

@@ -138,6 +138,18 @@ int tsamd_heldout_loglik(tsamd_ctx *ctx, uint32_t loc, double *sum, uint32_t *co
 int tsamd_comm_unique_id(uint8_t id[TSAMD_COMM_ID_BYTES]);
 int tsamd_comm_init(tsamd_ctx *ctx, const uint8_t id[TSAMD_COMM_ID_BYTES]);
 
+/* Peer-to-peer alternative to the RCCL all-reduce: each rank writes its 2K partial sums
+ * straight into every peer's exchange buffer over xGMI (IPC-mapped fine-grained memory)
+ * and the next pass adds the ranks' rows up in rank order, so the per-pass exchange costs
+ * a few microseconds instead of a collective launch.  Every rank calls tsamd_p2p_export,
+ * the handles of all ranks (rank order) are gathered over any side channel, every rank
+ * calls tsamd_p2p_connect; a barrier is needed before the first update and before destroy.
+ * All ranks must then issue identical call sequences (as with any collective).  A peer that
+ * stops responding surfaces as TSAMD_ECOMM from tsamd_synchronize after a bounded wait. */
+#define TSAMD_P2P_HANDLE_BYTES 64
+int tsamd_p2p_export(tsamd_ctx *ctx, uint8_t handle[TSAMD_P2P_HANDLE_BYTES]);
+int tsamd_p2p_connect(tsamd_ctx *ctx, const uint8_t *handles /* [world][TSAMD_P2P_HANDLE_BYTES] */);
+
 /* ---- measurement / synthetic workloads ---------------------------------------- */
 /* Pritchard-Stephens-Donnelly genotypes straight into HBM for columns
  * [first_loc, first_loc + n_locs): y ~ Binomial(2, sum_k theta[n][k] * beta[j][k]),

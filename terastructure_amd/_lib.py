@@ -8,6 +8,7 @@ from . import build as _build
 _HANDLE = None
 
 COMM_ID_BYTES = 128
+P2P_HANDLE_BYTES = 64
 FLAG_SPLIT_EPILOGUE = 1
 FLAG_NO_GRAPH = 2
 
@@ -59,6 +60,8 @@ SYMBOLS = {
     "tsamd_heldout_loglik": (_int, [_vp, _u32, _pd, _pu32]),
     "tsamd_comm_unique_id": (_int, [_pu8]),
     "tsamd_comm_init": (_int, [_vp, _pu8]),
+    "tsamd_p2p_export": (_int, [_vp, _pu8]),
+    "tsamd_p2p_connect": (_int, [_vp, _pu8]),
     "tsamd_synth_genotypes": (_int, [_vp, _pd, _pd, _u32, _u32, _u64, _dbl]),
     "tsamd_profile_enable": (_int, [_vp, _int]),
     "tsamd_profile_read": (_int, [_vp, _pu64, _pd, _pu64, _pd]),

@@ -87,6 +87,9 @@ struct tsamd_ctx {
   size_t stage_bytes = 0;
   std::map<uint32_t, HeldLoc> held;
   ncclComm_t comm = nullptr;
+  Xchg *xchg = nullptr;                    // peer-to-peer exchange buffer (fine-grained, IPC-exported)
+  std::vector<void *> peer_maps;           // hipIpcOpenMemHandle results to close
+  bool p2p = false;
   bool split = false;  // lambda_t leaves the pass via ctl->lt and the epilogue is its own kernel
   // profiling
   bool prof = false;
@@ -160,7 +163,9 @@ int enqueue_pass(tsamd_ctx *c, bool first) {
   if (c->split) {
     hipLaunchKernelGGL(ts_reduce_rows, dim3(1), dim3(256), 0, c->stream, c->p, par);
     Ctl *ctl = c->p.ctl;
-    if (c->comm) {
+    if (c->p2p) {
+      // ts_reduce_rows has already pushed the row to every peer
+    } else if (c->comm) {
       ncclResult_t r = g_rccl.AllReduce(ctl->lt[par], ctl->lt_sum[par], 2 * c->cfg.k, ncclDouble, ncclSum, c->comm,
                                         c->stream);
       if (r != ncclSuccess) return fail(c, TSAMD_ECOMM, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
@@ -333,6 +338,8 @@ void tsamd_destroy(tsamd_ctx *c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   destroy_graph(c);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  for (void *m : c->peer_maps) hipIpcCloseMemHandle(m);
+  if (c->xchg) hipFree(c->xchg);
   for (auto e : c->ev_pass) hipEventDestroy(e);
   for (auto e : c->ev_first) hipEventDestroy(e);
   hipFree(c->p.bed);
@@ -677,9 +684,9 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   CHECK_CTX(c);
   if (n == 0) return TSAMD_OK;
   if (!locs) return fail(c, TSAMD_EINVAL, "null schedule");
-  if (c->cfg.world > 1 && !c->comm)
-    return fail(c, TSAMD_ECOMM, "context is shard %u of %u but tsamd_comm_init has not been called", c->cfg.rank,
-                c->cfg.world);
+  if (c->cfg.world > 1 && !c->comm && !c->p2p)
+    return fail(c, TSAMD_ECOMM, "context is shard %u of %u but neither tsamd_comm_init nor tsamd_p2p_connect has been called",
+                c->cfg.rank, c->cfg.world);
   std::vector<uint32_t> ent(n);
   for (uint32_t i = 0; i < n; ++i) {
     if (locs[i] >= c->cfg.l) return fail(c, TSAMD_EINVAL, "schedule[%u] = %u >= l", i, locs[i]);
@@ -705,7 +712,8 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   // of kGraphSnps SNPs is replayed as often as needed; kernels past the end of the
   // schedule only carry the state forward.  (kGraphSnps is even, so a replay keeps the
   // launch parity.)
-  const bool use_graph = !(c->cfg.flags & TSAMD_FLAG_NO_GRAPH) && !c->comm && !c->prof && n >= kGraphSnps;
+  const bool use_graph =
+      !(c->cfg.flags & TSAMD_FLAG_NO_GRAPH) && (!c->comm || c->p2p) && !c->prof && n >= kGraphSnps;
   if (use_graph) {
     if (!c->graph_exec)
       if (int rc = build_graph(c, kGraphSnps)) return rc;
@@ -725,6 +733,11 @@ int tsamd_synchronize(tsamd_ctx *c) {
   HIP_TRY(c, hipSetDevice(c->dev));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->keepalive.clear();
+  if (c->p2p) {
+    unsigned long long err = 0;
+    HIP_TRY(c, hipMemcpy(&err, &c->xchg->error, sizeof err, hipMemcpyDeviceToHost));
+    if (err) return fail(c, TSAMD_ECOMM, "peer-to-peer exchange timed out waiting for a peer (epoch %llu)", err);
+  }
   if (c->prof) {
     for (uint32_t i = 0; i < c->n_ev_pass; ++i) {
       float ms = 0;
@@ -836,6 +849,56 @@ int tsamd_comm_init(tsamd_ctx *c, const uint8_t id[TSAMD_COMM_ID_BYTES]) {
   }
   c->split = true;
   c->p.rows_from_lt = 1u;
+  destroy_graph(c);
+  return TSAMD_OK;
+}
+
+int tsamd_p2p_export(tsamd_ctx *c, uint8_t handle[TSAMD_P2P_HANDLE_BYTES]) {
+  CHECK_CTX(c);
+  if (!handle) return fail(c, TSAMD_EINVAL, "null handle");
+  static_assert(sizeof(hipIpcMemHandle_t) == TSAMD_P2P_HANDLE_BYTES, "hipIpcMemHandle_t size");
+  if (c->cfg.world > (uint32_t)kMaxRanks) return fail(c, TSAMD_EUNSUPPORTED, "peer-to-peer exchange supports up to %d ranks", kMaxRanks);
+  HIP_TRY(c, hipSetDevice(c->dev));
+  if (!c->xchg) {
+    HIP_TRY(c, hipExtMallocWithFlags((void **)&c->xchg, sizeof(Xchg), hipDeviceMallocFinegrained));
+    HIP_TRY(c, hipMemset(c->xchg, 0, sizeof(Xchg)));
+  }
+  hipIpcMemHandle_t h;
+  HIP_TRY(c, hipIpcGetMemHandle(&h, c->xchg));
+  memcpy(handle, &h, sizeof h);
+  return TSAMD_OK;
+}
+
+int tsamd_p2p_connect(tsamd_ctx *c, const uint8_t *handles) {
+  CHECK_CTX(c);
+  if (!handles) return fail(c, TSAMD_EINVAL, "null handles");
+  if (!c->xchg) return fail(c, TSAMD_EINVAL, "tsamd_p2p_export has not been called");
+  if (c->p2p) return fail(c, TSAMD_EINVAL, "peer-to-peer exchange already connected");
+  HIP_TRY(c, hipSetDevice(c->dev));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (uint32_t q = 0; q < c->cfg.world; ++q) {
+    if (q == c->cfg.rank) {
+      c->p.peers[q] = c->xchg;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + (size_t)q * TSAMD_P2P_HANDLE_BYTES, sizeof h);
+    void *ptr = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      for (void *m : c->peer_maps) hipIpcCloseMemHandle(m);
+      c->peer_maps.clear();
+      return fail(c, TSAMD_ECOMM, "hipIpcOpenMemHandle(rank %u): %s", q, hipGetErrorString(e));
+    }
+    c->peer_maps.push_back(ptr);
+    c->p.peers[q] = (Xchg *)ptr;
+  }
+  c->p.xchg = c->xchg;
+  c->p.xchg_world = c->cfg.world;
+  c->p.xchg_rank = c->cfg.rank;
+  c->p.rows_from_lt = 0u;
+  c->split = true;
+  c->p2p = true;
   destroy_graph(c);
   return TSAMD_OK;
 }

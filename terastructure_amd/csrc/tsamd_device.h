@@ -34,6 +34,7 @@ struct State {
   uint32_t done;   // SNP complete: lam[loc] / eb[loc] in the global arrays are final
   uint32_t nrows;  // partial rows written by pass `iters`
   uint32_t pad;
+  unsigned long long epoch;  // launches of the state-machine sequence so far (tags peer exchanges)
   double lam[2 * TSAMD_MAX_K];  // !done: lambda[loc] before the pending pass' epilogue
   double eb[2 * TSAMD_MAX_K];   // exp(Elogbeta[loc]) used by pass `iters` (the last executed pass)
 };
@@ -45,6 +46,16 @@ struct Ctl {
   State st[2];
   double lt[2][2 * TSAMD_MAX_K];      // sharded: this shard's summed partial rows (all-reduce input)
   double lt_sum[2][2 * TSAMD_MAX_K];  // all-reduced; read as the single "row" of the previous pass
+};
+
+// Peer-to-peer exchange buffer of one rank (fine-grained, IPC-shared): every rank writes
+// its summed row for slot `parity` into rows[parity][source rank] of EVERY rank's buffer
+// over xGMI and then publishes seq[parity][source] = epoch with a system-scope release.
+constexpr int kMaxRanks = 16;
+struct Xchg {
+  double rows[2][kMaxRanks * 2 * TSAMD_MAX_K];  // [slot][source * J + j]
+  unsigned long long seq[2][kMaxRanks];
+  unsigned long long error;                     // a bounded wait gave up
 };
 
 struct DevParams {
@@ -64,7 +75,11 @@ struct DevParams {
   uint32_t chunk_first; // items (individuals, or pairs with TSAMD_FIRST_VEC=2) per workgroup of the first pass
   uint32_t K;
   uint32_t max_inner;
-  uint32_t rows_from_lt; // sharded: the previous pass' rows are the one all-reduced row ctl->lt_sum[parity^1]
+  uint32_t rows_from_lt; // sharded over RCCL: the previous pass' rows are the one all-reduced row ctl->lt_sum[parity^1]
+  uint32_t xchg_world;   // > 0: sharded over the peer-to-peer exchange: rows = xchg->rows[parity^1][0..world)
+  uint32_t xchg_rank;
+  Xchg *xchg;            // this rank's buffer
+  Xchg *peers[kMaxRanks]; // every rank's buffer as mapped into this process (peers[xchg_rank] == xchg)
   double alpha, eta0, eta1, nodetau0, nodekappa, gamma_scale, thresh;
 };
 

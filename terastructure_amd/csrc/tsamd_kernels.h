@@ -95,6 +95,7 @@ __device__ __forceinline__ void publish_complete(const DevParams &p, Ctl *ctl, c
       W->iters = S->iters;
       W->done = 1u;
       W->nrows = 0u;
+      W->epoch = S->epoch + 1ull;
     }
   }
 }
@@ -113,7 +114,26 @@ __device__ __forceinline__ void carry_state(const State *S, State *W, uint32_t J
     W->iters = S->iters;
     W->done = S->done;
     W->nrows = S->nrows;
+    W->epoch = S->epoch + 1ull;
   }
+}
+
+// Sharded over the peer-to-peer exchange: wait (bounded) until every rank's row of the
+// previous launch has landed in this rank's buffer.  Called by all threads of a workgroup.
+__device__ __forceinline__ void wait_peer_rows(const DevParams &p, uint32_t slot, unsigned long long epoch) {
+  const uint32_t tid = threadIdx.x;
+  if (tid < p.xchg_world) {
+    const unsigned long long *flag = &p.xchg->seq[slot][tid];
+    const unsigned long long t0 = wall_clock64();  // 100 MHz
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 300000000ull) {  // 3 s: a peer died; report instead of hanging
+        __hip_atomic_store(&p.xchg->error, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
 }
 
 // w[k] = exp(psi(g[k])) * exp(r_min) = A_k * exp(r_min - r_k): Elogtheta exponentiated
@@ -227,11 +247,14 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par) {
   const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
   const uint32_t siters = S->iters, snrows = S->nrows;
   const uint32_t sched_len = ctl->sched_len;
-  const double *rowsR = p.rows_from_lt ? ctl->lt_sum[par ^ 1u] : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
-  const uint32_t nrowsR = p.rows_from_lt ? 1u : snrows;
+  const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
+                        : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
+                                         : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
+  const uint32_t nrowsR = p.xchg_world ? p.xchg_world : p.rows_from_lt ? 1u : snrows;
   double *rowsW = p.partials + (size_t)par * kMaxGrid * J;
 
   const bool pending = svalid != 0u && sdone == 0u;
+  if (pending && p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch);
   uint32_t loc, hol, idx, iters;
   bool do_gamma = false;
   uint32_t prev_loc = 0;
@@ -456,6 +479,7 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par) {
       W->iters = iters;
       W->done = 0u;
       W->nrows = gridDim.x;
+      W->epoch = S->epoch + 1ull;
     }
   }
 }
@@ -474,8 +498,11 @@ __global__ __launch_bounds__(256) void ts_flush(DevParams p, uint32_t par) {
   State *W = &ctl->st[par];
   const uint32_t J = 2 * p.K;
   if (S->valid != 0u && S->done == 0u) {
-    const double *rowsR = p.rows_from_lt ? ctl->lt_sum[par ^ 1u] : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
-    const uint32_t nrowsR = p.rows_from_lt ? 1u : S->nrows;
+    if (p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch);
+    const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
+                          : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
+                                           : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
+    const uint32_t nrowsR = p.xchg_world ? p.xchg_world : p.rows_from_lt ? 1u : S->nrows;
     finish_pending<256>(p, S, rowsR, nrowsR, J, s_fin, s_lam, s_eb, s_diff, &s_flag);
     publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
   } else {
@@ -521,10 +548,21 @@ __global__ __launch_bounds__(256) void ts_reduce_rows(DevParams p, uint32_t par)
   }
   s_fin[tid] = v;
   __syncthreads();
+  double lt = 0.0;
   if (tid < J) {
-    double lt = 0.0;
     for (uint32_t rr = 0; rr < R; ++rr) lt += s_fin[rr * J + tid];
     ctl->lt[par][tid] = lt;
+  }
+  if (p.xchg_world && nrows > 0u) {
+    // one 8-byte store per (peer, j) over xGMI, then the epoch flag with system-scope release
+    if (tid < J)
+      for (uint32_t q = 0; q < p.xchg_world; ++q)
+        __hip_atomic_store(&p.peers[q]->rows[par][p.xchg_rank * J + tid], lt, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (tid < p.xchg_world)
+      __hip_atomic_store(&p.peers[tid]->seq[par][p.xchg_rank], W->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

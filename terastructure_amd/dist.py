@@ -29,6 +29,14 @@ def bootstrap_comm(engine, dist):
     engine.comm_init(uid[0])
 
 
+def bootstrap_p2p(engine, dist):
+    """Map every rank's exchange buffer into every rank (tsamd_p2p_export / _connect)."""
+    handles = [None] * dist.get_world_size()
+    dist.all_gather_object(handles, engine.p2p_export())
+    engine.p2p_connect(handles)
+    dist.barrier()
+
+
 def shard_bounds(n, world, shard_range):
     """[(begin, count)] for every rank."""
     return [shard_range(n, r, world) for r in range(world)]

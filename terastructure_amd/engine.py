@@ -188,6 +188,18 @@ class Engine:
         buf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(uid)
         self._check(self.h.tsamd_comm_init(self.ctx, buf))
 
+    def p2p_export(self):
+        buf = (C.c_uint8 * _lib.P2P_HANDLE_BYTES)()
+        self._check(self.h.tsamd_p2p_export(self.ctx, buf))
+        return bytes(buf)
+
+    def p2p_connect(self, handles):
+        """handles: list of world byte strings in rank order (tsamd_p2p_export of every rank)."""
+        blob = b"".join(handles)
+        assert len(blob) == self.world * _lib.P2P_HANDLE_BYTES
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        self._check(self.h.tsamd_p2p_connect(self.ctx, buf))
+
     # -- measurement ------------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self.h.tsamd_profile_enable(self.ctx, int(on)))

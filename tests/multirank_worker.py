@@ -1,0 +1,55 @@
+"""One rank of the sharded engine (launched by test_gpu_multirank.py, RANK / WORLD_SIZE /
+MASTER_* in the environment).  All ranks may share one GPU (TS_DEVICE): the peer-to-peer
+exchange only needs IPC-mapped buffers, which also works between processes on one device."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main():
+    import terastructure_amd as ts
+    from terastructure_amd import dist as tdist
+    from helpers import init_gamma, pack_bed, psd_genotypes
+
+    out_dir, mode = sys.argv[1], sys.argv[2]
+    n, l, k, seed, nsnp = (int(x) for x in sys.argv[3:8])
+    d, rank, world = tdist.init_process_group("gloo")
+    device = int(os.environ.get("TS_DEVICE", rank))
+    y, _, _ = psd_genotypes(n, l, k, seed, 0.03)
+    payload = pack_bed(y)
+    gamma = init_gamma(n, k, seed + 1)
+    eng = ts.Engine(n, l, k, device=device, rank=rank, world=world)
+    b, c = eng.shard_begin, eng.shard_count
+    eng.upload_bed(payload)
+    eng.set_gamma(gamma[b:b + c])
+    rng = np.random.default_rng(seed + 2)
+    for loc in rng.choice(l, size=max(1, l // 8), replace=False):
+        cand = np.nonzero(y[loc] != 3)[0]
+        eng.set_heldout(int(loc), rng.choice(cand, size=max(1, n // 50), replace=False))
+    if mode == "p2p":
+        tdist.bootstrap_p2p(eng, d)
+    else:
+        tdist.bootstrap_comm(eng, d)
+    locs = np.random.default_rng(seed + 3).integers(0, l, size=nsnp).astype(np.uint32)
+    eng.run_schedule(locs[:5])          # eager path
+    eng.synchronize()
+    its = [eng.snp_update(int(locs[5]))]
+    eng.run_schedule(locs[6:])          # graph replay path when long enough
+    eng.synchronize()
+    full = tdist.gather_rows(eng.get_gamma(), n, d, ts.shard_range)
+    cnt = tdist.gather_rows(eng.get_counts().astype(np.float64)[:, None], n, d, ts.shard_range)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), lam=eng.get_lambda(), gamma=full, cnt=cnt, its=np.array(its),
+             passes=eng.total_passes())
+    d.barrier()
+    eng.close()
+    d.barrier()
+    d.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

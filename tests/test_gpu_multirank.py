@@ -1,0 +1,72 @@
+"""Sharded engine across several processes.  The development box has one GPU, so the
+ranks share device 0: that exercises the whole multi-rank protocol (shard slicing, epoch
+tagged peer-to-peer exchange through IPC-mapped buffers, replicated epilogue, graph
+replay) except the xGMI hop itself."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_py as op
+from helpers import init_gamma, pack_bed, psd_genotypes, rel_err
+
+pytestmark = [pytest.mark.gpu, pytest.mark.spawns]
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_ranks(tmp_path, mode, world, n, l, k, seed, nsnp):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TS_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), str(tmp_path), mode,
+                                       str(n), str(l), str(k), str(seed), str(nsnp)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
+    return [np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,n,k", [(2, 3000, 6), (4, 5003, 8), (3, 1000, 3)])
+def test_p2p_sharded_matches_oracle(tmp_path, world, n, k):
+    l, seed, nsnp = 32, 91, 40
+    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp)
+    y, _, _ = psd_genotypes(n, l, k, seed, 0.03)
+    orc = op.Oracle(n, l, k)
+    orc.load_bed_payload(pack_bed(y))
+    orc.set_gamma(init_gamma(n, k, seed + 1))
+    rng = np.random.default_rng(seed + 2)
+    for loc in rng.choice(l, size=max(1, l // 8), replace=False):
+        cand = np.nonzero(y[loc] != 3)[0]
+        orc.set_heldout(int(loc), rng.choice(cand, size=max(1, n // 50), replace=False))
+    locs = np.random.default_rng(seed + 3).integers(0, l, size=nsnp)
+    its = [orc.snp_update(int(loc)) for loc in locs]
+    for r in res:
+        assert rel_err(r["lam"], orc.lambda_()) < 1e-9
+        assert rel_err(r["gamma"], orc.gamma()) < 1e-9
+        assert np.array_equal(r["cnt"][:, 0], orc.c_indiv())
+        assert int(r["its"][0]) == its[5]
+        assert int(r["passes"]) == sum(its)
+    for r in res[1:]:   # replicated state is bitwise identical on every rank
+        assert np.array_equal(r["lam"], res[0]["lam"])
