@@ -10,9 +10,10 @@ step of that SNP, :695-740), on synthetic PSD genotypes resident in HBM.
 N > 1 is launched by the driver as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 one rank per GPU; individuals are sharded across ranks and the per-pass
-lambda statistics are all-reduced by RCCL inside libtsamd (strong scaling:
-N individuals fixed).  torch.distributed (gloo) only carries the RCCL unique
-id and the timing barriers.
+lambda statistics are exchanged inside libtsamd -- peer-to-peer stores over xGMI
+when the start-up self-test passes, RCCL all-reduce otherwise (strong scaling:
+N individuals fixed).  torch.distributed (gloo) only carries the bootstrap
+handles and the timing barriers.
 """
 import argparse
 import json
@@ -34,9 +35,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--n", type=int, default=1_000_000, help="individuals (global)")
-    ap.add_argument("--l", type=int, default=1_000_000, help="SNP locations (capped to what fits in HBM)")
-    ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--individuals", "--n", dest="n", type=int, default=1_000_000, help="individuals (global)")
+    ap.add_argument("--snps", "--l", dest="l", type=int, default=1_000_000,
+                    help="SNP locations (capped to what fits in HBM)")
+    ap.add_argument("--pops", "--k", dest="k", type=int, default=8)
     ap.add_argument("--seed", type=int, default=20240607)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
@@ -62,31 +64,38 @@ def choose_exchange(ts, dist, rank, world, local_rank, k):
     gamma = rng.gamma(100.0, 0.01, size=(n, k))
     locs = np.array([3, 1, 3, 7, 0, 5], dtype=np.uint32)
     out = {}
-    ok = 1.0
     for mode in ("rccl", "p2p"):
+        out[mode] = None
+        e = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
         try:
-            with ts.Engine(n, l, k, device=local_rank, rank=rank, world=world) as e:
-                b, c = e.shard_begin, e.shard_count
-                e.synth_genotypes(theta[b:b + c], beta, seed=11)
-                e.set_gamma(gamma[b:b + c])
+            b, c = e.shard_begin, e.shard_count
+            e.synth_genotypes(theta[b:b + c], beta, seed=11)
+            e.set_gamma(gamma[b:b + c])
+            try:
                 (tdist.bootstrap_p2p if mode == "p2p" else tdist.bootstrap_comm)(e, dist)
+            except Exception as exc:  # noqa: BLE001 -- raised on every rank together
+                if rank == 0:
+                    print(f"[bench] exchange self-test, {mode}: {exc}", file=sys.stderr, flush=True)
+                continue
+            res, err = None, None
+            try:
                 e.run_schedule(locs)
                 e.synchronize()
-                out[mode] = (e.get_lambda(), e.get_gamma())
-                dist.barrier()
-        except Exception as exc:  # noqa: BLE001 -- any failure means: do not use this mode
-            if rank == 0:
-                print(f"[bench] exchange self-test, mode {mode}: {exc}", file=sys.stderr, flush=True)
-            out[mode] = None
-            if mode == "p2p":
-                ok = 0.0
+                res = (e.get_lambda(), e.get_gamma())
+            except Exception as exc:  # noqa: BLE001
+                err = exc
+            if tdist.all_ok(err is None, dist):
+                out[mode] = res
+            elif rank == 0:
+                print(f"[bench] exchange self-test, {mode}: run failed ({err})", file=sys.stderr, flush=True)
+        finally:
+            dist.barrier()
+            e.close()
+            dist.barrier()
+    ok = out["p2p"] is not None
     if ok and out["rccl"] is not None:
-        for a, b_ in zip(out["rccl"], out["p2p"]):
-            if not np.allclose(a, b_, rtol=1e-10, atol=0):
-                ok = 0.0
-    t = torch.tensor([ok], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return "p2p" if t.item() > 0 else "rccl"
+        ok = all(np.allclose(a, b_, rtol=1e-10, atol=0) for a, b_ in zip(out["rccl"], out["p2p"]))
+    return "p2p" if tdist.all_ok(ok, dist) else "rccl"
 
 
 def main():
@@ -94,6 +103,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "TSAMD_BENCH_DEVICE" in os.environ:  # development only: several ranks on one GPU
+        local_rank = int(os.environ["TSAMD_BENCH_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")

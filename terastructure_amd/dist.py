@@ -29,12 +29,34 @@ def bootstrap_comm(engine, dist):
     engine.comm_init(uid[0])
 
 
+def all_ok(ok, dist):
+    """True iff `ok` holds on every rank (one collective; call it unconditionally)."""
+    import torch
+
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return t.item() > 0
+
+
 def bootstrap_p2p(engine, dist):
-    """Map every rank's exchange buffer into every rank (tsamd_p2p_export / _connect)."""
+    """Map every rank's exchange buffer into every rank (tsamd_p2p_export / _connect).
+    Raises on EVERY rank if any rank failed, so callers can fall back together."""
+    err = None
+    try:
+        mine = engine.p2p_export()
+    except Exception as exc:  # noqa: BLE001
+        mine, err = b"", exc
     handles = [None] * dist.get_world_size()
-    dist.all_gather_object(handles, engine.p2p_export())
-    engine.p2p_connect(handles)
-    dist.barrier()
+    dist.all_gather_object(handles, mine)
+    if err is None and all(len(h) == len(mine) and h for h in handles):
+        try:
+            engine.p2p_connect(handles)
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+    elif err is None:
+        err = RuntimeError("a peer could not export its exchange buffer")
+    if not all_ok(err is None, dist):
+        raise RuntimeError(f"peer-to-peer exchange unavailable: {err or 'a peer failed'}")
 
 
 def shard_bounds(n, world, shard_range):
