@@ -94,7 +94,7 @@ def test_initial_state_matches_init_lambda(ts):
         assert rel_err(eng.get_elogtheta(), orc.elogtheta()) < 1e-12
 
 
-@pytest.mark.parametrize("k", [2, 3, 4, 6, 8, 12, 20])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 6, 8, 12, 20, 32])
 def test_single_pass_known_answer(ts, k):
     """One pass of phi + lambda_t + epilogue (max_inner = 1): rel 1e-12."""
     n, l = 2500, 6
@@ -143,7 +143,7 @@ def test_hol_mode_suppresses_step(ts):
         assert eng.get_counts().max() == 2  # steps of loc 1 and loc 2 only
 
 
-@pytest.mark.parametrize("n,l,k", [(200, 40, 3), (1000, 64, 6), (5000, 48, 8), (3001, 32, 20)])
+@pytest.mark.parametrize("n,l,k", [(200, 40, 3), (1000, 64, 6), (5000, 48, 8), (3001, 32, 20), (70000, 24, 5), (2000, 16, 31)])
 def test_trajectory_matches_oracle(ts, n, l, k):
     eng, orc, _ = make_pair(ts, n, l, k, 1000 + n)
     rng = np.random.default_rng(n)
