@@ -102,6 +102,7 @@ struct tsamd_ctx {
   hipGraphExec_t graph_exec = nullptr;
   uint32_t graph_snps = 0, graph_par0 = 0;
   uint64_t q = 0;  // kernels of the state-machine sequence launched so far (parity = q & 1)
+  uint32_t prev_rows = 0;  // grid of the last pass kernel enqueued (row-count hint for the next)
   std::vector<std::vector<uint32_t>> keepalive;  // host schedules of copies possibly still in flight
   std::string err;
 };
@@ -133,7 +134,7 @@ int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
   if (!(ctx)) return TSAMD_EINVAL
 
 // launchers of the K-specialised kernels, one per translation unit (tsamd_inst.hip)
-#define TSAMD_DECL(k) void launch_k##k(int, uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t);
+#define TSAMD_DECL(k) void launch_k##k(int, uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, uint32_t);
 #define TSAMD_ALL_K(X)                                                                             \
   X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)     \
   X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
@@ -156,10 +157,14 @@ uint32_t next_parity(tsamd_ctx *c) { return (uint32_t)(c->q++ & 1u); }
 // one pass = ts_pass [+ ts_reduce_rows + all-reduce when sharded]
 int enqueue_pass(tsamd_ctx *c, bool first) {
   const uint32_t par = next_parity(c);
+  // rows of the previous launch of the sequence: a first pass follows a plain pass (or a
+  // kernel that left nothing pending), a plain pass follows the first pass or a plain pass
+  const uint32_t hint = c->prev_rows;
   if (first)
-    kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p, par);
+    kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p, par, hint);
   else
-    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p, par);
+    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p, par, hint);
+  c->prev_rows = first ? c->grid_first : c->grid;
   if (c->split) {
     hipLaunchKernelGGL(ts_reduce_rows, dim3(1), dim3(256), 0, c->stream, c->p, par);
     Ctl *ctl = c->p.ctl;
@@ -238,6 +243,7 @@ void destroy_graph(tsamd_ctx *c) {
 int build_graph(tsamd_ctx *c, uint32_t snps) {
   destroy_graph(c);
   c->graph_par0 = (uint32_t)(c->q & 1u);  // kernel arguments (parity bits) are frozen at capture
+  c->prev_rows = c->grid;                 // in replay the first kernel follows a plain pass (or nothing pending)
   HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = TSAMD_OK;
   for (uint32_t s = 0; s < snps && rc == TSAMD_OK; ++s) rc = enqueue_snp(c);
@@ -421,7 +427,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
     const char *s = getenv(name);
     return (s && *s) ? (uint32_t)std::max(0, atoi(s)) : dflt;
   };
-  uint32_t block = env_u32("TSAMD_BLOCK", cfg->k <= 16 ? 512 : 256);
+  uint32_t block = env_u32("TSAMD_BLOCK", (cfg->k <= 16 && p.npairs >= 256u * 1024u) ? 512 : 256);
   if (block != 256u && block != 512u && block != 1024u) block = 256u;
   if (block == 1024u && cfg->k > 8) block = 512u;  // register budget of the pipelined loop
   auto geometry = [&](uint32_t nitems, uint32_t blk, uint32_t target, uint32_t &chunk, uint32_t &grid) {
@@ -583,7 +589,7 @@ int tsamd_set_gamma(tsamd_ctx *c, const double *gamma) {
     if (!(gamma[i] > 0.0) || !std::isfinite(gamma[i])) return fail(c, TSAMD_EINVAL, "gamma[%zu] must be positive and finite", i);
   HIP_TRY(c, hipSetDevice(c->dev));
   if (int rc = upload_kmajor(c, gamma, c->p.gam, 1.0)) return rc;
-  kLaunchers[c->cfg.k](kLaunchRefresh, 0, 0, c->stream, c->p, 0);
+  kLaunchers[c->cfg.k](kLaunchRefresh, 0, 0, c->stream, c->p, 0, 0);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSAMD_OK;

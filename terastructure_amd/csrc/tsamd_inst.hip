@@ -13,22 +13,22 @@
 namespace tsamd {
 
 void TSAMD_CAT(launch_k, TSAMD_K)(int which, uint32_t grid, uint32_t block, hipStream_t stream, const DevParams &p,
-                                  uint32_t par) {
+                                  uint32_t par, uint32_t nrows_hint) {
   constexpr int K = TSAMD_K;
   switch (which) {
     case kLaunchPass:
       if (block == 1024)
-        hipLaunchKernelGGL((ts_pass<K, false, 1024, 2>), dim3(grid), dim3(1024), 0, stream, p, par);
+        hipLaunchKernelGGL((ts_pass<K, false, 1024, 2>), dim3(grid), dim3(1024), 0, stream, p, par, nrows_hint);
       else if (block == 512)
-        hipLaunchKernelGGL((ts_pass<K, false, 512, 2>), dim3(grid), dim3(512), 0, stream, p, par);
+        hipLaunchKernelGGL((ts_pass<K, false, 512, 2>), dim3(grid), dim3(512), 0, stream, p, par, nrows_hint);
       else
-        hipLaunchKernelGGL((ts_pass<K, false, 256, 2>), dim3(grid), dim3(256), 0, stream, p, par);
+        hipLaunchKernelGGL((ts_pass<K, false, 256, 2>), dim3(grid), dim3(256), 0, stream, p, par, nrows_hint);
       break;
     case kLaunchFirst:
       if (block == 1)  // TSAMD_FIRST_VEC=2: two individuals per thread
-        hipLaunchKernelGGL((ts_pass<K, true, 256, 2>), dim3(grid), dim3(256), 0, stream, p, par);
+        hipLaunchKernelGGL((ts_pass<K, true, 256, 2>), dim3(grid), dim3(256), 0, stream, p, par, nrows_hint);
       else
-        hipLaunchKernelGGL((ts_pass<K, true, 256, 1>), dim3(grid), dim3(256), 0, stream, p, par);
+        hipLaunchKernelGGL((ts_pass<K, true, 256, 1>), dim3(grid), dim3(256), 0, stream, p, par, nrows_hint);
       break;
     default:
       hipLaunchKernelGGL((ts_refresh_w<K>), dim3((p.npairs + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, p);

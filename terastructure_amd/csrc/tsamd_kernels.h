@@ -25,23 +25,61 @@ namespace tsamd {
 // Fixed summation order: thread (r, j) adds rows r, r+R, ... (R = BLOCK / J), then
 // r = 0..R-1.  Outputs in LDS: s_lam = new lambda[loc], s_eb = new exp(Elogbeta[loc]).
 // Returns (uniformly) whether the SNP is complete (converged or max_inner passes run).
+// Fixed-order partial row sum: thread (r, j) adds rows r, r+R, ... (R = BLOCK / J), eight
+// loads in flight at a time.  issue() only starts the first eight loads, so that the
+// caller can queue other loads behind them (loads return in order: what is needed first
+// must be issued first); finish() adds them up and walks the remaining rows.
 template <int BLOCK>
-__device__ __forceinline__ bool finish_pending(const DevParams &p, const State *S, const double *rows,
-                                               uint32_t nrows, uint32_t J, double *s_fin, double *s_lam,
-                                               double *s_eb, double *s_diff, uint32_t *s_flag) {
+struct RowSum {
+  double t[8];
+  const double *rows;
+  uint32_t nrows, J, R, j, r;
+  __device__ __forceinline__ void issue(const double *rows_, uint32_t nrows_, uint32_t J_) {
+    rows = rows_;
+    nrows = nrows_;
+    J = J_;
+    R = BLOCK / J;
+    j = threadIdx.x % J;
+    r = threadIdx.x / J;
+    const uint32_t last = nrows > 0u ? nrows - 1u : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = rows[(size_t)min(r + (uint32_t)u * R, last) * J + j];
+  }
+  __device__ __forceinline__ double finish() {
+    double v = 0.0;
+    if (r >= R) return v;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += (r + (uint32_t)u * R < nrows) ? t[u] : 0.0;
+    for (uint32_t g0 = r + 8u * R; g0 < nrows; g0 += 8u * R) {
+      double s[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] = rows[(size_t)min(g0 + (uint32_t)u * R, nrows - 1u) * J + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += (g0 + (uint32_t)u * R < nrows) ? s[u] : 0.0;
+    }
+    return v;
+  }
+};
+
+template <int BLOCK>
+__device__ __forceinline__ double row_partial_sum(const double *rows, uint32_t nrows, uint32_t J) {
+  RowSum<BLOCK> rs;
+  rs.issue(rows, nrows, J);
+  return rs.finish();
+}
+
+// Finish the pending pass described by S from the per-thread partial row sums v (see
+// RowSum; then r = 0..R-1): lambda_t[j] = eb_used[j] * sum_rows, then update_lambda +
+// estimate_beta + convergence test (src/snpsamplinge.cc:356-364, :267-296; abs_mean
+// src/matrix.hh:885-893).  Called by ALL threads of a workgroup.
+// Outputs in LDS: s_lam = new lambda[loc], s_eb = new exp(Elogbeta[loc]).
+// Returns (uniformly) whether the SNP is complete (converged or max_inner passes run).
+template <int BLOCK>
+__device__ __forceinline__ bool finish_pending(const DevParams &p, const State *S, double v, uint32_t J,
+                                               double *s_fin, double *s_lam, double *s_eb, double *s_diff,
+                                               uint32_t *s_flag) {
   const uint32_t tid = threadIdx.x;
   const uint32_t R = BLOCK / J;
-  const uint32_t j = tid % J, r = tid / J;
-  double v = 0.0;
-  if (r < R) {
-    for (uint32_t g0 = r; g0 < nrows; g0 += 8u * R) {
-      double t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = rows[(size_t)min(g0 + (uint32_t)u * R, nrows - 1u) * J + j];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v += (g0 + (uint32_t)u * R < nrows) ? t[u] : 0.0;
-    }
-  }
   s_fin[tid] = v;
   __syncthreads();
   double nw = 0.0;
@@ -205,7 +243,7 @@ struct Lanes<2> {
 // population row and 2*VEC bits of the 2-bit column.  The plain pass uses VEC = 2; the
 // first pass, which also carries the gamma step, uses VEC = 1 to halve its registers.
 template <int KT, bool FIRST, int BLOCK, int VEC>
-__global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par) {
+__global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par, uint32_t nrows_hint) {
   constexpr int kWaves = BLOCK / 64;
   using LN = Lanes<VEC>;
   using WT = typename LN::T;
@@ -237,8 +275,13 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par) {
     for (int k = 0; k < KT; ++k) wv[k] = reinterpret_cast<const WT *>(p.w + (size_t)k * np)[i];
   };
 
-  // the first item's row loads do not depend on the state machine: get them in flight
-  // before the prologue's dependent loads
+  // Loads that do not depend on the state machine go first, so that they overlap its
+  // dependent loads.  Order matters (loads return in order): the previous launch's partial
+  // rows -- needed by the prologue; single GPU only; nrows_hint is that launch's grid size, a
+  // launch-time constant -- then the first item's row data.
+  const bool local_rows = p.xchg_world == 0u && p.rows_from_lt == 0u;
+  RowSum<BLOCK> rowsum;
+  rowsum.issue(p.partials + (size_t)(par ^ 1u) * kMaxGrid * (2 * KT), local_rows ? nrows_hint : 0u, 2 * KT);
   WT bufA[KT];
   const uint32_t i0 = begin + tid;
   if (!FIRST && i0 < end) load_rows(i0, bufA);
@@ -255,6 +298,8 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par) {
 
   const bool pending = svalid != 0u && sdone == 0u;
   if (pending && p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch);
+  double vrow = 0.0;
+  if (pending) vrow = (local_rows && nrowsR == nrows_hint) ? rowsum.finish() : row_partial_sum<BLOCK>(rowsR, nrowsR, J);
   uint32_t loc, hol, idx, iters;
   bool do_gamma = false;
   uint32_t prev_loc = 0;
@@ -264,7 +309,7 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par) {
       if (blockIdx.x == 0) carry_state(S, W, J);
       return;
     }
-    const bool complete = finish_pending<BLOCK>(p, S, rowsR, nrowsR, J, s_fin, s_lam, s_eb, s_diff, &s_flag);
+    const bool complete = finish_pending<BLOCK>(p, S, vrow, J, s_fin, s_lam, s_eb, s_diff, &s_flag);
     if (complete) {
       if (blockIdx.x == 0) publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
       return;
@@ -275,7 +320,7 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par) {
     iters = siters + 1u;
   } else {
     idx = sidx + 1u;  // 0xffffffff + 1 = 0: first SNP of the schedule
-    if (pending) finish_pending<BLOCK>(p, S, rowsR, nrowsR, J, s_fin, s_plam, s_peb, s_diff, &s_flag);
+    if (pending) finish_pending<BLOCK>(p, S, vrow, J, s_fin, s_plam, s_peb, s_diff, &s_flag);
     if (idx >= sched_len) {  // schedule exhausted: complete what is pending, carry state
       if (blockIdx.x == 0) {
         if (pending)
@@ -503,7 +548,7 @@ __global__ __launch_bounds__(256) void ts_flush(DevParams p, uint32_t par) {
                           : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
                                            : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
     const uint32_t nrowsR = p.xchg_world ? p.xchg_world : p.rows_from_lt ? 1u : S->nrows;
-    finish_pending<256>(p, S, rowsR, nrowsR, J, s_fin, s_lam, s_eb, s_diff, &s_flag);
+    finish_pending<256>(p, S, row_partial_sum<256>(rowsR, nrowsR, J), J, s_fin, s_lam, s_eb, s_diff, &s_flag);
     publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
   } else {
     carry_state(S, W, J);
@@ -535,17 +580,7 @@ __global__ __launch_bounds__(256) void ts_reduce_rows(DevParams p, uint32_t par)
   const uint32_t nrows = (W->valid != 0u && W->done == 0u) ? W->nrows : 0u;
   const double *rows = p.partials + (size_t)par * kMaxGrid * J;
   const uint32_t R = 256u / J;
-  const uint32_t j = tid % J, r = tid / J;
-  double v = 0.0;
-  if (r < R && nrows > 0u) {
-    for (uint32_t g0 = r; g0 < nrows; g0 += 8u * R) {
-      double t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = rows[(size_t)min(g0 + (uint32_t)u * R, nrows - 1u) * J + j];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v += (g0 + (uint32_t)u * R < nrows) ? t[u] : 0.0;
-    }
-  }
+  const double v = row_partial_sum<256>(rows, nrows, J);
   s_fin[tid] = v;
   __syncthreads();
   double lt = 0.0;
@@ -590,6 +625,6 @@ __global__ __launch_bounds__(kBlock) void ts_refresh_w(DevParams p) {
 // (tsamd_inst.hip compiled with -DTSAMD_K=<k>) defines tsamd::launch_k<k>.
 enum LaunchWhich { kLaunchPass = 0, kLaunchFirst = 1, kLaunchRefresh = 2 };
 using LaunchFn = void (*)(int which, uint32_t grid, uint32_t block, hipStream_t stream, const DevParams &p,
-                          uint32_t par);
+                          uint32_t par, uint32_t nrows_hint);
 
 }  // namespace tsamd
