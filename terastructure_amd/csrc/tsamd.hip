@@ -165,12 +165,10 @@ int enqueue_pass(tsamd_ctx *c, bool first) {
   else
     kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p, par, hint);
   c->prev_rows = first ? c->grid_first : c->grid;
-  if (c->split) {
+  if (c->split && !c->p2p) {  // (peer-to-peer: every workgroup has already pushed its row to every rank)
     hipLaunchKernelGGL(ts_reduce_rows, dim3(1), dim3(256), 0, c->stream, c->p, par);
     Ctl *ctl = c->p.ctl;
-    if (c->p2p) {
-      // ts_reduce_rows has already pushed the row to every peer
-    } else if (c->comm) {
+    if (c->comm) {
       ncclResult_t r = g_rccl.AllReduce(ctl->lt[par], ctl->lt_sum[par], 2 * c->cfg.k, ncclDouble, ncclSum, c->comm,
                                         c->stream);
       if (r != ncclSuccess) return fail(c, TSAMD_ECOMM, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
@@ -258,6 +256,32 @@ int build_graph(tsamd_ctx *c, uint32_t snps) {
   HIP_TRY(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
   c->graph_snps = snps;
   return TSAMD_OK;
+}
+
+uint32_t env_u32(const char *name, uint32_t dflt) {
+  const char *s = getenv(name);
+  return (s && *s) ? (uint32_t)std::max(0, atoi(s)) : dflt;
+}
+
+// Launch geometry.  The pass kernel is a streaming reduction: enough waves per CU to cover
+// HBM latency, but few workgroups, because every workgroup of the NEXT launch adds all
+// partial rows up again (and, sharded peer-to-peer, every workgroup sends its row to every
+// rank: max_grid = kXchgBlocks there).
+void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
+  DevParams &p = c->p;
+  uint32_t block = env_u32("TSAMD_BLOCK", (c->cfg.k <= 16 && p.npairs >= 256u * 1024u) ? 512 : 256);
+  if (block != 256u && block != 512u && block != 1024u) block = 256u;
+  if (block == 1024u && c->cfg.k > 8) block = 512u;  // register budget of the pipelined loop
+  auto geometry = [&](uint32_t nitems, uint32_t blk, uint32_t target, uint32_t &chunk, uint32_t &grid) {
+    target = std::min<uint32_t>(std::max<uint32_t>(target, 1u), max_grid);
+    chunk = (nitems + target - 1) / target;
+    chunk = (chunk + blk - 1) / blk * blk;
+    grid = (nitems + chunk - 1) / chunk;
+  };
+  c->block = block;
+  c->first_vec = env_u32("TSAMD_FIRST_VEC", 1) == 2 ? 2 : 1;
+  geometry(p.npairs, block, env_u32("TSAMD_GRID", 256), p.chunk, c->grid);
+  geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", 512), p.chunk_first, c->grid_first);
 }
 
 int ensure_stage(tsamd_ctx *c, size_t bytes) {
@@ -390,7 +414,12 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   c->dev = cfg->device;
   c->n_begin = b;
   c->n_local = cnt;
-  c->npad = (cnt + 511u) / 512u * 512u;
+  {
+    // every rank pads to the same width, so that all ranks run the same launch geometry
+    uint32_t b0 = 0, width = 0;
+    tsamd_shard_range(cfg->n, 0, cfg->world, &b0, &width);
+    c->npad = (std::max(width, cnt) + 511u) / 512u * 512u;
+  }
 #define CREATE_TRY(expr)                                                                          \
   do {                                                                                            \
     hipError_t e_ = (expr);                                                                       \
@@ -420,26 +449,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   p.gamma_scale = cfg->gamma_scale;
   p.thresh = cfg->conv_thresh;
 
-  // Launch geometry.  The pass kernel is a streaming reduction: enough waves per CU to
-  // cover HBM latency, but few workgroups, because every workgroup costs one arrival on
-  // the ticket and one partial row for the last workgroup to add up.
-  auto env_u32 = [](const char *name, uint32_t dflt) {
-    const char *s = getenv(name);
-    return (s && *s) ? (uint32_t)std::max(0, atoi(s)) : dflt;
-  };
-  uint32_t block = env_u32("TSAMD_BLOCK", (cfg->k <= 16 && p.npairs >= 256u * 1024u) ? 512 : 256);
-  if (block != 256u && block != 512u && block != 1024u) block = 256u;
-  if (block == 1024u && cfg->k > 8) block = 512u;  // register budget of the pipelined loop
-  auto geometry = [&](uint32_t nitems, uint32_t blk, uint32_t target, uint32_t &chunk, uint32_t &grid) {
-    target = std::min<uint32_t>(std::max<uint32_t>(target, 1u), kMaxGrid);
-    chunk = (nitems + target - 1) / target;
-    chunk = (chunk + blk - 1) / blk * blk;
-    grid = (nitems + chunk - 1) / chunk;
-  };
-  c->block = block;
-  c->first_vec = env_u32("TSAMD_FIRST_VEC", 1) == 2 ? 2 : 1;
-  geometry(p.npairs, block, env_u32("TSAMD_GRID", 256), p.chunk, c->grid);
-  geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", 512), p.chunk_first, c->grid_first);
+  configure_launch(c, kMaxGrid);
   p.rows_from_lt = c->split ? 1u : 0u;
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
@@ -905,6 +915,7 @@ int tsamd_p2p_connect(tsamd_ctx *c, const uint8_t *handles) {
   c->p.rows_from_lt = 0u;
   c->split = true;
   c->p2p = true;
+  configure_launch(c, kXchgBlocks);
   destroy_graph(c);
   return TSAMD_OK;
 }

@@ -48,14 +48,18 @@ struct Ctl {
   double lt_sum[2][2 * TSAMD_MAX_K];  // all-reduced; read as the single "row" of the previous pass
 };
 
-// Peer-to-peer exchange buffer of one rank (fine-grained, IPC-shared): every rank writes
-// its summed row for slot `parity` into rows[parity][source rank] of EVERY rank's buffer
-// over xGMI and then publishes seq[parity][source] = epoch with a system-scope release.
+// Peer-to-peer exchange buffer of one rank (fine-grained, IPC-shared).  Every workgroup of
+// a pass kernel writes its partial row for slot `parity` into
+// rows[parity][(source rank * nblk + workgroup) * J ..] of EVERY rank's buffer over xGMI and
+// then publishes seq[parity][source rank * nblk + workgroup] = epoch with a system-scope
+// release; the next launch's prologue waits for world * nblk flags and adds the rows in
+// that fixed order.  Pass kernels therefore run with at most kXchgBlocks workgroups.
 constexpr int kMaxRanks = 16;
+constexpr int kXchgBlocks = 64;
 struct Xchg {
-  double rows[2][kMaxRanks * 2 * TSAMD_MAX_K];  // [slot][source * J + j]
-  unsigned long long seq[2][kMaxRanks];
-  unsigned long long error;                     // a bounded wait gave up
+  double rows[2][kMaxRanks * kXchgBlocks * 2 * TSAMD_MAX_K];
+  unsigned long long seq[2][kMaxRanks * kXchgBlocks];
+  unsigned long long error;  // a bounded wait gave up
 };
 
 struct DevParams {

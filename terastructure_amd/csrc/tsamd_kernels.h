@@ -156,15 +156,16 @@ __device__ __forceinline__ void carry_state(const State *S, State *W, uint32_t J
   }
 }
 
-// Sharded over the peer-to-peer exchange: wait (bounded) until every rank's row of the
-// previous launch has landed in this rank's buffer.  Called by all threads of a workgroup.
-__device__ __forceinline__ void wait_peer_rows(const DevParams &p, uint32_t slot, unsigned long long epoch) {
-  const uint32_t tid = threadIdx.x;
-  if (tid < p.xchg_world) {
-    const unsigned long long *flag = &p.xchg->seq[slot][tid];
+// Sharded over the peer-to-peer exchange: wait (bounded) until all nflags partial rows of
+// the previous launch (world ranks x its workgroups) have landed in this rank's buffer.
+// Called by all threads of a workgroup.
+__device__ __forceinline__ void wait_peer_rows(const DevParams &p, uint32_t slot, unsigned long long epoch,
+                                               uint32_t nflags) {
+  for (uint32_t t = threadIdx.x; t < nflags; t += blockDim.x) {
+    const unsigned long long *flag = &p.xchg->seq[slot][t];
     const unsigned long long t0 = wall_clock64();  // 100 MHz
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-      __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_s_sleep(4);
       if (wall_clock64() - t0 > 300000000ull) {  // 3 s: a peer died; report instead of hanging
         __hip_atomic_store(&p.xchg->error, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
@@ -293,11 +294,11 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par, uint
   const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                         : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
                                          : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
-  const uint32_t nrowsR = p.xchg_world ? p.xchg_world : p.rows_from_lt ? 1u : snrows;
+  const uint32_t nrowsR = p.xchg_world ? p.xchg_world * snrows : p.rows_from_lt ? 1u : snrows;
   double *rowsW = p.partials + (size_t)par * kMaxGrid * J;
 
   const bool pending = svalid != 0u && sdone == 0u;
-  if (pending && p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch);
+  if (pending && p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
   double vrow = 0.0;
   if (pending) vrow = (local_rows && nrowsR == nrows_hint) ? rowsum.finish() : row_partial_sum<BLOCK>(rowsR, nrowsR, J);
   uint32_t loc, hol, idx, iters;
@@ -506,7 +507,21 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par, uint
     double v = s_red[0][tid];
 #pragma unroll
     for (int wv = 1; wv < kWaves; ++wv) v += s_red[wv][tid];
-    rowsW[(size_t)blockIdx.x * J + tid] = v;  // read by the NEXT launch only
+    if (p.xchg_world == 0u) {
+      rowsW[(size_t)blockIdx.x * J + tid] = v;  // read by the NEXT launch only
+    } else {
+      // straight into every rank's exchange buffer (one 8-byte store per value and peer)
+      const size_t at = ((size_t)p.xchg_rank * gridDim.x + blockIdx.x) * J + tid;
+      for (uint32_t q = 0; q < p.xchg_world; ++q)
+        __hip_atomic_store(&p.peers[q]->rows[par][at], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
+  }
+  if (p.xchg_world) {
+    __syncthreads();
+    if (tid < p.xchg_world)
+      __hip_atomic_store(&p.peers[tid]->seq[par][p.xchg_rank * gridDim.x + blockIdx.x], S->epoch + 1ull,
+                         __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 
   // workgroup 0 publishes the state the next launch starts from
@@ -543,11 +558,11 @@ __global__ __launch_bounds__(256) void ts_flush(DevParams p, uint32_t par) {
   State *W = &ctl->st[par];
   const uint32_t J = 2 * p.K;
   if (S->valid != 0u && S->done == 0u) {
-    if (p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch);
+    const uint32_t nrowsR = p.xchg_world ? p.xchg_world * S->nrows : p.rows_from_lt ? 1u : S->nrows;
+    if (p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
     const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                           : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
                                            : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
-    const uint32_t nrowsR = p.xchg_world ? p.xchg_world : p.rows_from_lt ? 1u : S->nrows;
     finish_pending<256>(p, S, row_partial_sum<256>(rowsR, nrowsR, J), J, s_fin, s_lam, s_eb, s_diff, &s_flag);
     publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
   } else {
@@ -583,21 +598,10 @@ __global__ __launch_bounds__(256) void ts_reduce_rows(DevParams p, uint32_t par)
   const double v = row_partial_sum<256>(rows, nrows, J);
   s_fin[tid] = v;
   __syncthreads();
-  double lt = 0.0;
   if (tid < J) {
+    double lt = 0.0;
     for (uint32_t rr = 0; rr < R; ++rr) lt += s_fin[rr * J + tid];
     ctl->lt[par][tid] = lt;
-  }
-  if (p.xchg_world && nrows > 0u) {
-    // one 8-byte store per (peer, j) over xGMI, then the epoch flag with system-scope release
-    if (tid < J)
-      for (uint32_t q = 0; q < p.xchg_world; ++q)
-        __hip_atomic_store(&p.peers[q]->rows[par][p.xchg_rank * J + tid], lt, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
-    __syncthreads();
-    if (tid < p.xchg_world)
-      __hip_atomic_store(&p.peers[tid]->seq[par][p.xchg_rank], W->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
