@@ -93,16 +93,22 @@ __device__ __forceinline__ bool finish_pending(const DevParams &p, const State *
     s_diff[tid] = fabs(nw - old);
   }
   __syncthreads();
-  if (tid < J) {
-    const double s = s_lam[tid & ~1u] + s_lam[tid | 1u];
-    s_eb[tid] = exp(digamma(nw) - digamma(s));
-  }
+  // psi(lambda_kt) on threads [0, J) and psi(lambda_k0 + lambda_k1) on threads [J, J + K) in
+  // ONE instruction stream: the two digamma chains of estimate_beta run side by side
+  const bool is_sum = tid >= J && tid < J + J / 2;
+  double x = nw;
+  if (is_sum) x = s_lam[2 * (tid - J)] + s_lam[2 * (tid - J) + 1];
+  const double psi_x = (tid < J + J / 2) ? digamma(x) : 0.0;
+  if (is_sum) s_fin[tid - J] = psi_x;
+  const double psi_own = psi_x;
   if (tid == 0) {
     double d = 0.0;
     for (uint32_t jj = 0; jj < J; ++jj) d += s_diff[jj];
     d /= (double)J;
     *s_flag = (d < p.thresh || S->iters >= p.max_inner) ? 1u : 0u;
   }
+  __syncthreads();
+  if (tid < J) s_eb[tid] = exp(psi_own - s_fin[tid >> 1]);
   __syncthreads();
   return *s_flag != 0u;
 }
