@@ -307,3 +307,41 @@ def test_config1_reference_fixture(ts):
         assert abs(sd / cnt - so / cnt) < 1e-9
         assert np.max(np.abs(eng.get_theta() - orc.theta())) <= 1e-6
         assert rel_err(eng.get_gamma(), orc.gamma()) < 1e-7
+
+
+def test_full_size_invariants(ts):
+    """BASELINE size (N = 1M individuals, K = 8): properties that need no oracle.
+    Every phi row sums to 1, so per pass  sum_k lambda_t[k][0] = sum_n y_n  and
+    sum_k lambda_t[k][1] = sum_n (2 - y_n)  over observed genotypes; one gamma step maps a
+    row sum S to (1-rho) S + rho (K alpha + 2 L) with rho = (2 + c_n)^-1/2; theta rows sum
+    to 1; and a re-run is bit-identical."""
+    n, l, k = 1_000_000, 8, 8
+    rng = np.random.default_rng(123)
+    theta = rng.dirichlet(np.full(k, 0.2), size=n)
+    beta = rng.uniform(0.05, 0.95, size=(l, k))
+    g0 = rng.gamma(100.0, 0.01, size=(n, k))
+    outs = []
+    for rep in range(2):
+        with ts.Engine(n, l, k) as eng:
+            eng.synth_genotypes(theta, beta, seed=99, missing_rate=0.01)
+            eng.set_gamma(g0)
+            cols = [unpack_bed(eng.download_bed(j)[None, :], n)[0] for j in (2, 5)]
+            assert eng.snp_update(2) == 10
+            lam = eng.get_lambda(2, 1)[0]
+            y = cols[0].astype(np.int64)
+            ok = y != 3
+            assert abs((lam[:, 0] - 1.0).sum() - y[ok].sum()) <= 1e-9 * y[ok].sum()
+            assert abs((lam[:, 1] - 1.0).sum() - (2 - y[ok]).sum()) <= 1e-9 * (2 - y[ok]).sum()
+            assert 0.005 < (~ok).mean() < 0.015                  # ~1 % missing as requested
+            eng.snp_update(5)                                      # applies the step of location 2
+            g1 = eng.get_gamma()
+            rho = 2.0 ** -0.5
+            want = np.where(ok, (1 - rho) * g0.sum(1) + rho * (k * (1.0 / k) + 2 * l), g0.sum(1))
+            assert np.max(np.abs(g1.sum(1) - want) / want) < 1e-12
+            assert np.array_equal(eng.get_counts(), ok.astype(np.uint32))
+            th = eng.get_theta()
+            assert np.max(np.abs(th.sum(1) - 1.0)) < 1e-12 and th.min() > 0
+            eb = eng.get_ebeta()
+            assert eb.min() > 0 and eb.max() < 1
+            outs.append((eng.get_lambda(), g1))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
