@@ -20,7 +20,7 @@ MAX_K = 32
 HEADERS = [os.path.join(CSRC, "tsamd_kernels.h"), os.path.join(CSRC, "tsamd_generic_kernels.h"), os.path.join(CSRC, "tsamd_device.h"),
            os.path.join(ROOT, "include", "tsamd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("TSAMD_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():

@@ -451,6 +451,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
 
   configure_launch(c, kMaxGrid);
   p.rows_from_lt = c->split ? 1u : 0u;
+  p.sweep_alternate = env_u32("TSAMD_SWEEP", 1) ? 1u : 0u;
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
   CREATE_TRY(hipMalloc((void **)&p.w, K * np * sizeof(double)));

@@ -79,6 +79,7 @@ struct DevParams {
   uint32_t chunk_first; // items (individuals, or pairs with TSAMD_FIRST_VEC=2) per workgroup of the first pass
   uint32_t K;
   uint32_t max_inner;
+  uint32_t sweep_alternate; // plain passes alternate their sweep direction (L2 reuse); TSAMD_SWEEP=0 disables
   uint32_t rows_from_lt; // sharded over RCCL: the previous pass' rows are the one all-reduced row ctl->lt_sum[parity^1]
   uint32_t xchg_world;   // > 0: sharded over the peer-to-peer exchange: rows = xchg->rows[parity^1][0..world)
   uint32_t xchg_rank;

@@ -249,8 +249,11 @@ struct Lanes<2> {
 // Item i of a workgroup's chunk is VEC consecutive individuals: one 8*VEC-byte load per
 // population row and 2*VEC bits of the 2-bit column.  The plain pass uses VEC = 2; the
 // first pass, which also carries the gamma step, uses VEC = 1 to halve its registers.
+#ifndef TSAMD_FIRST_WAVES
+#define TSAMD_FIRST_WAVES 1
+#endif
 template <int KT, bool FIRST, int BLOCK, int VEC>
-__global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par, uint32_t nrows_hint) {
+__global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1) void ts_pass(DevParams p, uint32_t par, uint32_t nrows_hint) {
   constexpr int kWaves = BLOCK / 64;
   using LN = Lanes<VEC>;
   using WT = typename LN::T;
@@ -289,9 +292,15 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par, uint
   const bool local_rows = p.xchg_world == 0u && p.rows_from_lt == 0u;
   RowSum<BLOCK> rowsum;
   rowsum.issue(p.partials + (size_t)(par ^ 1u) * kMaxGrid * (2 * KT), local_rows ? nrows_hint : 0u, 2 * KT);
+  // Plain passes sweep their chunk forwards and backwards alternately (the launch parity
+  // alternates): the tail of the previous sweep is still in this XCD's L2 (4 MB) when the
+  // next one starts there.
   WT bufA[KT];
   const uint32_t i0 = begin + tid;
-  if (!FIRST && i0 < end) load_rows(i0, bufA);
+  const uint32_t cnt = (i0 < end) ? (end - i0 + BLOCK - 1u) / BLOCK : 0u;  // this thread's items
+  const bool rev = !FIRST && (par & 1u) != 0u && p.sweep_alternate != 0u;
+  auto item = [&](uint32_t t) { return rev ? i0 + (cnt - 1u - t) * BLOCK : i0 + t * BLOCK; };
+  if (!FIRST && cnt) load_rows(item(0), bufA);
   __builtin_amdgcn_sched_barrier(0);
 
   const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
@@ -416,27 +425,27 @@ __global__ __launch_bounds__(BLOCK) void ts_pass(DevParams p, uint32_t par, uint
     };
     WT bufB[KT];
     uint32_t wordA = 0, wordB = 0;
-    uint32_t i = i0;
-    if (i < end) {
-      wordA = col[i / kItemsPerWord];
+    if (cnt) {
+      wordA = col[item(0) / kItemsPerWord];
+      uint32_t t = 0;
       while (true) {
-        const uint32_t i1 = i + BLOCK;
-        const uint32_t j1 = i1 < end ? i1 : i;
+        const uint32_t t1 = t + 1u;
+        const uint32_t j1 = item(t1 < cnt ? t1 : t);
         load_rows(j1, bufB);
         wordB = col[j1 / kItemsPerWord];
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the arithmetic
-        consume(i, bufA, wordA);
+        consume(item(t), bufA, wordA);
         __builtin_amdgcn_sched_barrier(0);
-        if (i1 >= end) break;
-        const uint32_t i2 = i1 + BLOCK;
-        const uint32_t j2 = i2 < end ? i2 : i1;
+        if (t1 >= cnt) break;
+        const uint32_t t2 = t + 2u;
+        const uint32_t j2 = item(t2 < cnt ? t2 : t1);
         load_rows(j2, bufA);
         wordA = col[j2 / kItemsPerWord];
         __builtin_amdgcn_sched_barrier(0);
-        consume(i1, bufB, wordB);
+        consume(item(t1), bufB, wordB);
         __builtin_amdgcn_sched_barrier(0);
-        if (i2 >= end) break;
-        i = i2;
+        if (t2 >= cnt) break;
+        t = t2;
       }
     }
   } else {
