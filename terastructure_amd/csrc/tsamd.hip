@@ -916,7 +916,7 @@ int tsamd_p2p_connect(tsamd_ctx *c, const uint8_t *handles) {
   c->p.rows_from_lt = 0u;
   c->split = true;
   c->p2p = true;
-  configure_launch(c, kXchgBlocks);
+  configure_launch(c, std::max<uint32_t>(16u, std::min<uint32_t>(kXchgBlocks, 512u / c->cfg.world)));
   destroy_graph(c);
   return TSAMD_OK;
 }

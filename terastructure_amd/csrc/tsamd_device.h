@@ -53,9 +53,11 @@ struct Ctl {
 // rows[parity][(source rank * nblk + workgroup) * J ..] of EVERY rank's buffer over xGMI and
 // then publishes seq[parity][source rank * nblk + workgroup] = epoch with a system-scope
 // release; the next launch's prologue waits for world * nblk flags and adds the rows in
-// that fixed order.  Pass kernels therefore run with at most kXchgBlocks workgroups.
+// that fixed order.  Pass kernels then run with at most 512 / world workgroups (every
+// workgroup of the next launch polls all flags and re-adds all rows), never more than
+// kXchgBlocks.
 constexpr int kMaxRanks = 16;
-constexpr int kXchgBlocks = 64;
+constexpr int kXchgBlocks = 256;
 struct Xchg {
   double rows[2][kMaxRanks * kXchgBlocks * 2 * TSAMD_MAX_K];
   unsigned long long seq[2][kMaxRanks * kXchgBlocks];
