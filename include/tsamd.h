@@ -61,7 +61,7 @@ typedef struct tsamd_config {
   uint32_t flags;       /* TSAMD_FLAG_* */
 } tsamd_config;
 
-#define TSAMD_FLAG_SPLIT_EPILOGUE 1u /* run the sharded kernel sequence (row sum -> exchange) even on one GPU */
+#define TSAMD_FLAG_SPLIT_EPILOGUE 1u /* run the sharded kernel sequence (pass, row sum, exchange) even on one GPU */
 #define TSAMD_FLAG_NO_GRAPH 2u       /* tsamd_run_schedule launches eagerly instead of replaying a hipGraph */
 
 int tsamd_abi_version(void);

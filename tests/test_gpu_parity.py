@@ -182,8 +182,8 @@ def test_run_schedule_equals_snp_updates_bitwise(ts):
 
 
 def test_split_epilogue_path_bitwise(ts):
-    """The multi-GPU kernel sequence (pass -> exchange -> epilogue kernel) with one shard
-    gives the same bits as the fused single-GPU pass."""
+    """The sharded kernel sequence (pass -> row sum -> exchange) with one shard gives the
+    same bits as the single-GPU sequence."""
     n, l, k = 3000, 32, 6
     locs = np.random.default_rng(4).integers(0, l, size=20).astype(np.uint32)
     res = []
