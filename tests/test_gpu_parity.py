@@ -307,6 +307,14 @@ def test_config1_reference_fixture(ts):
         assert abs(sd / cnt - so / cnt) < 1e-9
         assert np.max(np.abs(eng.get_theta() - orc.theta())) <= 1e-6
         assert rel_err(eng.get_gamma(), orc.gamma()) < 1e-7
+        # and against the committed golden vectors of the same run (tests/golden/make_golden.py)
+        from conftest import GOLDEN
+
+        g = np.load(os.path.join(GOLDEN, "config1_oracle.npz"))
+        assert np.array_equal(g["locs"], locs) and np.array_equal(g["held_locs"], orc.heldout_locs())
+        assert np.max(np.abs(eng.get_theta() - g["theta1050"])) <= 1e-6
+        assert rel_err(eng.get_gamma(), g["gamma1050"]) < 1e-7
+        assert rel_err(eng.get_lambda()[locs[:8]], g["lam_sample"]) < 1e-7
 
 
 def test_full_size_invariants(ts):

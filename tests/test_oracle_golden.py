@@ -89,6 +89,7 @@ def config1_run():
     o = op.Oracle(200, 10000, 3)
     o.read_bed_file(os.path.join(REF_DATA, "test.bed"))
     res = o.run(seed=1234, reportfreq=1000)
+    res["theta"], res["gamma"] = o.theta(), o.gamma()  # snapshots: later tests keep using the state
     return o, res
 
 
@@ -137,3 +138,18 @@ def test_config1_against_reference_fixtures(config1_run):
     beta = o.ebeta()[:, list(perm)]
     tb = np.loadtxt(os.path.join(REF_DATA, "oracle_beta.txt"))
     assert np.sqrt(np.mean(((1 - beta) - tb) ** 2)) <= 0.05
+
+
+def test_oracle_matches_committed_golden(config1_run):
+    """tests/golden/config1_oracle.npz (made by tests/golden/make_golden.py) pins the oracle
+    build: same compiler flags, same bits."""
+    from conftest import GOLDEN
+
+    g = np.load(os.path.join(GOLDEN, "config1_oracle.npz"))
+    o, res = config1_run
+    assert int(g["final_iter"]) == res["final_iter"] == 16050
+    assert np.array_equal(g["val_iters"], np.array([x[0] for x in res["lines"]]))
+    assert np.allclose(g["val_mean_ll"], np.array([x[1] for x in res["lines"]]), rtol=0, atol=1e-12)
+    assert np.allclose(g["final_theta"], res["theta"], rtol=0, atol=1e-12)
+    assert np.allclose(g["final_gamma"], res["gamma"], rtol=1e-12, atol=0)
+    assert "%.9f" % (g["val_ll"].sum() / 1000) == "-0.732008912"
