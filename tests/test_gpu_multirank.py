@@ -70,3 +70,30 @@ def test_p2p_sharded_matches_oracle(tmp_path, world, n, k):
         assert int(r["passes"]) == sum(its)
     for r in res[1:]:   # replicated state is bitwise identical on every rank
         assert np.array_equal(r["lam"], res[0]["lam"])
+
+
+def test_p2p_long_schedule_matches_single_gpu(tmp_path):
+    """Stress: 2 ranks, 100K individuals, 300 updates through the graph-replayed
+    peer-to-peer path (3000 epoch-tagged exchanges) against the single-GPU engine."""
+    n, l, k, seed, nsnp = 100_000, 48, 8, 17, 300
+    res = _run_ranks(tmp_path, "p2p", 2, n, l, k, seed, nsnp)   # children first: this process has not touched HIP yet
+    import terastructure_amd as ts
+
+    y, _, _ = psd_genotypes(n, l, k, seed, 0.03)
+    with ts.Engine(n, l, k) as eng:
+        eng.upload_bed(pack_bed(y))
+        eng.set_gamma(init_gamma(n, k, seed + 1))
+        rng = np.random.default_rng(seed + 2)
+        for loc in rng.choice(l, size=max(1, l // 8), replace=False):
+            cand = np.nonzero(y[loc] != 3)[0]
+            eng.set_heldout(int(loc), rng.choice(cand, size=max(1, n // 50), replace=False))
+        locs = np.random.default_rng(seed + 3).integers(0, l, size=nsnp).astype(np.uint32)
+        eng.run_schedule(locs)
+        eng.synchronize()
+        lam, gam, cnt, passes = eng.get_lambda(), eng.get_gamma(), eng.get_counts(), eng.total_passes()
+    for r in res:
+        assert rel_err(r["lam"], lam) < 1e-9
+        assert rel_err(r["gamma"], gam) < 1e-9
+        assert np.array_equal(r["cnt"][:, 0], cnt)
+        assert int(r["passes"]) == passes
+    assert np.array_equal(res[0]["lam"], res[1]["lam"])
