@@ -293,8 +293,8 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   RowSum<BLOCK> rowsum;
   rowsum.issue(p.partials + (size_t)(par ^ 1u) * kMaxGrid * (2 * KT), local_rows ? nrows_hint : 0u, 2 * KT);
   // Plain passes sweep their chunk forwards and backwards alternately (the launch parity
-  // alternates): the tail of the previous sweep is still in this XCD's L2 (4 MB) when the
-  // next one starts there.
+  // alternates): a pass starts on the addresses the previous one touched last (measured
+  // 13.1 -> 11.1 us at N = 1M, K = 8; TSAMD_SWEEP=0 disables).
   WT bufA[KT];
   const uint32_t i0 = begin + tid;
   const uint32_t cnt = (i0 < end) ? (end - i0 + BLOCK - 1u) / BLOCK : 0u;  // this thread's items
