@@ -9,11 +9,13 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 template <int VAR>
-__global__ __launch_bounds__(256) void rd(const double2 *__restrict__ a, size_t npairs, uint32_t chunk, double *out) {
+__global__ __launch_bounds__(256) void rd(const double2 *__restrict__ a, size_t npairs, uint32_t chunk, double *out, int rev) {
   const uint32_t begin = blockIdx.x * chunk;
   const uint32_t end = min((size_t)begin + chunk, npairs);
   double acc = 0.0;
-  for (uint32_t i = begin + threadIdx.x; i < end; i += 256) {
+  const uint32_t cnt = (end - begin) / 256;
+  for (uint32_t t = 0; t < cnt; ++t) {
+    const uint32_t i = begin + threadIdx.x + (rev ? (cnt - 1 - t) : t) * 256;
     double2 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -38,14 +40,17 @@ int main() {
     CK(hipMalloc(&a, bytes)); CK(hipMalloc(&out, 8));
     CK(hipMemset(a, 0, bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int var = 0; var < 3; ++var)
-      for (uint32_t grid : {256u, 512u, 1024u, 2048u, 4096u}) {
+    for (int alt = 0; alt < 2; ++alt)
+    for (int var = 1; var < 3; ++var)
+      for (uint32_t grid : {256u, 512u, 1024u}) {
         uint32_t chunk = (npairs + grid - 1) / grid; chunk = (chunk + 255) / 256 * 256;
         const uint32_t g = (npairs + chunk - 1) / chunk;
+        int flip = 0;
         auto launch = [&]() {
-          if (var == 0) hipLaunchKernelGGL(rd<0>, dim3(g), dim3(256), 0, 0, a, npairs, chunk, out);
-          else if (var == 1) hipLaunchKernelGGL(rd<1>, dim3(g), dim3(256), 0, 0, a, npairs, chunk, out);
-          else hipLaunchKernelGGL(rd<2>, dim3(g), dim3(256), 0, 0, a, npairs, chunk, out);
+          const int rev = alt ? (flip ^= 1) : 0;
+          if (var == 0) hipLaunchKernelGGL(rd<0>, dim3(g), dim3(256), 0, 0, a, npairs, chunk, out, rev);
+          else if (var == 1) hipLaunchKernelGGL(rd<1>, dim3(g), dim3(256), 0, 0, a, npairs, chunk, out, rev);
+          else hipLaunchKernelGGL(rd<2>, dim3(g), dim3(256), 0, 0, a, npairs, chunk, out, rev);
         };
         for (int w = 0; w < 3; ++w) launch();
         CK(hipEventRecord(e0, 0));
@@ -54,7 +59,7 @@ int main() {
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("size %4zu MB var %d grid %4u: %.2f us/launch  %.0f GB/s\n", mb, var, g, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e9);
+        printf("size %4zu MB alt %d var %d grid %4u: %.2f us/launch  %.0f GB/s\n", mb, alt, var, g, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e9);
       }
     CK(hipFree(a)); CK(hipFree(out));
   }
