@@ -38,7 +38,8 @@ extern "C" {
 #define TSAMD_ECOMM (-4)        /* RCCL error / communicator missing */
 #define TSAMD_EUNSUPPORTED (-5) /* e.g. K above the compiled maximum */
 
-#define TSAMD_MAX_K 32
+#define TSAMD_MAX_K 128          /* populations; K <= TSAMD_SPECIALIZED_K runs the K-specialised kernels, */
+#define TSAMD_SPECIALIZED_K 32  /* larger K a slower run-time-K fallback */
 #define TSAMD_COMM_ID_BYTES 128
 
 typedef struct tsamd_ctx tsamd_ctx;

@@ -18,6 +18,7 @@
 #define TSAMD_MAIN_TU 1
 #include "tsamd_generic_kernels.h"
 #include "tsamd_kernels.h"
+#include "tsamd_wide_kernels.h"
 
 using namespace tsamd;
 
@@ -79,6 +80,7 @@ struct tsamd_ctx {
   int dev = 0;
   hipStream_t stream = nullptr;
   uint32_t n_begin = 0, n_local = 0, npad = 0;
+  bool wide = false;  // K above TSAMD_SPECIALIZED_K: run-time-K fallback kernels (tsamd_wide_kernels.h)
   uint32_t grid = 0, block = 256, grid_first = 0, first_vec = 1;  // plain-pass and first-pass launch geometry
   DevParams p{};
   uint32_t *d_sched = nullptr;
@@ -144,7 +146,7 @@ TSAMD_ALL_K(TSAMD_DECL)
 }
 namespace {
 #define TSAMD_ENTRY(k) tsamd::launch_k##k,
-const LaunchFn kLaunchers[TSAMD_MAX_K + 1] = {nullptr, TSAMD_ALL_K(TSAMD_ENTRY)};
+const LaunchFn kLaunchers[TSAMD_SPECIALIZED_K + 1] = {nullptr, TSAMD_ALL_K(TSAMD_ENTRY)};
 
 __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -160,11 +162,17 @@ int enqueue_pass(tsamd_ctx *c, bool first) {
   // rows of the previous launch of the sequence: a first pass follows a plain pass (or a
   // kernel that left nothing pending), a plain pass follows the first pass or a plain pass
   const uint32_t hint = c->prev_rows;
-  if (first)
+  if (c->wide) {
+    if (first)
+      hipLaunchKernelGGL((ts_pass_wide<true>), dim3(c->grid_first), dim3(kWideBlock), 0, c->stream, c->p, par, hint);
+    else
+      hipLaunchKernelGGL((ts_pass_wide<false>), dim3(c->grid_first), dim3(kWideBlock), 0, c->stream, c->p, par, hint);
+    c->prev_rows = c->grid_first;
+  } else if (first)
     kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p, par, hint);
   else
     kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p, par, hint);
-  c->prev_rows = first ? c->grid_first : c->grid;
+  if (!c->wide) c->prev_rows = first ? c->grid_first : c->grid;
   if (c->split && !c->p2p) {  // (peer-to-peer: every workgroup has already pushed its row to every rank)
     hipLaunchKernelGGL(ts_reduce_rows, dim3(1), dim3(256), 0, c->stream, c->p, par);
     Ctl *ctl = c->p.ctl;
@@ -181,12 +189,12 @@ int enqueue_pass(tsamd_ctx *c, bool first) {
 }
 
 void enqueue_begin(tsamd_ctx *c, uint32_t n, bool drop_pending) {
-  hipLaunchKernelGGL(ts_begin, dim3(1), dim3(64), 0, c->stream, c->p.ctl, n, next_parity(c), 2 * c->cfg.k,
+  hipLaunchKernelGGL(ts_begin, dim3(1), dim3(256), 0, c->stream, c->p.ctl, n, next_parity(c), 2 * c->cfg.k,
                      drop_pending ? 1u : 0u);
 }
 
 void enqueue_flush(tsamd_ctx *c) {
-  hipLaunchKernelGGL(ts_flush, dim3(1), dim3(256), 0, c->stream, c->p, next_parity(c));
+  hipLaunchKernelGGL(ts_flush, dim3(1), dim3(512), 0, c->stream, c->p, next_parity(c));
 }
 
 // profiling: one HIP-event pair around the first pass and one around the run of plain
@@ -269,6 +277,14 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
 // rank: max_grid = kXchgBlocks there).
 void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
   DevParams &p = c->p;
+  if (c->wide) {  // one individual per thread, at most kWideItems individuals per thread
+    uint32_t chunk = (p.npad + max_grid - 1) / max_grid;
+    chunk = (chunk + kWideBlock - 1) / kWideBlock * kWideBlock;
+    p.chunk_first = p.chunk = chunk;
+    c->grid_first = c->grid = (p.npad + chunk - 1) / chunk;
+    c->block = kWideBlock;
+    return;
+  }
   uint32_t block = env_u32("TSAMD_BLOCK", (c->cfg.k <= 16 && p.npairs >= 256u * 1024u) ? 512 : 256);
   if (block != 256u && block != 512u && block != 1024u) block = 256u;
   if (block == 1024u && c->cfg.k > 8) block = 512u;  // register budget of the pipelined loop
@@ -449,7 +465,14 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   p.gamma_scale = cfg->gamma_scale;
   p.thresh = cfg->conv_thresh;
 
+  c->wide = cfg->k > TSAMD_SPECIALIZED_K;
   configure_launch(c, kMaxGrid);
+  if (c->wide && p.chunk_first > (uint32_t)kWideBlock * kWideItems) {
+    fail(nullptr, TSAMD_EUNSUPPORTED, "k = %u (wide-K fallback) supports at most %u individuals per GPU", cfg->k,
+         (unsigned)(kMaxGrid * kWideBlock * kWideItems));
+    tsamd_destroy(c);
+    return TSAMD_EUNSUPPORTED;
+  }
   p.rows_from_lt = c->split ? 1u : 0u;
   p.sweep_alternate = env_u32("TSAMD_SWEEP", 1) ? 1u : 0u;
 
@@ -600,7 +623,10 @@ int tsamd_set_gamma(tsamd_ctx *c, const double *gamma) {
     if (!(gamma[i] > 0.0) || !std::isfinite(gamma[i])) return fail(c, TSAMD_EINVAL, "gamma[%zu] must be positive and finite", i);
   HIP_TRY(c, hipSetDevice(c->dev));
   if (int rc = upload_kmajor(c, gamma, c->p.gam, 1.0)) return rc;
-  kLaunchers[c->cfg.k](kLaunchRefresh, 0, 0, c->stream, c->p, 0, 0);
+  if (c->wide)
+    hipLaunchKernelGGL(ts_refresh_w_wide, dim3((c->npad + 255) / 256), dim3(256), 0, c->stream, c->p);
+  else
+    kLaunchers[c->cfg.k](kLaunchRefresh, 0, 0, c->stream, c->p, 0, 0);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSAMD_OK;
@@ -917,6 +943,8 @@ int tsamd_p2p_connect(tsamd_ctx *c, const uint8_t *handles) {
   c->split = true;
   c->p2p = true;
   configure_launch(c, std::max<uint32_t>(16u, std::min<uint32_t>(kXchgBlocks, 512u / c->cfg.world)));
+  if (c->wide && c->p.chunk_first > (uint32_t)kWideBlock * kWideItems)
+    return fail(c, TSAMD_EUNSUPPORTED, "wide-K fallback: shard too large for the peer-to-peer launch geometry");
   destroy_graph(c);
   return TSAMD_OK;
 }

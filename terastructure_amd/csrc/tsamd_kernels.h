@@ -95,12 +95,18 @@ __device__ __forceinline__ bool finish_pending(const DevParams &p, const State *
   __syncthreads();
   // psi(lambda_kt) on threads [0, J) and psi(lambda_k0 + lambda_k1) on threads [J, J + K) in
   // ONE instruction stream: the two digamma chains of estimate_beta run side by side
-  const bool is_sum = tid >= J && tid < J + J / 2;
-  double x = nw;
-  if (is_sum) x = s_lam[2 * (tid - J)] + s_lam[2 * (tid - J) + 1];
-  const double psi_x = (tid < J + J / 2) ? digamma(x) : 0.0;
-  if (is_sum) s_fin[tid - J] = psi_x;
-  const double psi_own = psi_x;
+  double psi_own;
+  if (J + J / 2 <= (uint32_t)BLOCK) {
+    const bool is_sum = tid >= J && tid < J + J / 2;
+    double x = nw;
+    if (is_sum) x = s_lam[2 * (tid - J)] + s_lam[2 * (tid - J) + 1];
+    const double psi_x = (tid < J + J / 2) ? digamma(x) : 0.0;
+    if (is_sum) s_fin[tid - J] = psi_x;
+    psi_own = psi_x;
+  } else {  // wide K in a small workgroup: one chain after the other
+    psi_own = (tid < J) ? digamma(nw) : 0.0;
+    if (tid < J / 2) s_fin[tid] = digamma(s_lam[2 * tid] + s_lam[2 * tid + 1]);
+  }
   if (tid == 0) {
     double d = 0.0;
     for (uint32_t jj = 0; jj < J; ++jj) d += s_diff[jj];
@@ -562,8 +568,8 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
 #ifdef TSAMD_MAIN_TU  // K-independent kernels: compiled into tsamd.hip only
 // End of a schedule: complete the pending pass so that lambda/eb in the global arrays are
 // final (whole SNPs only are ever enqueued, so the pending pass is the SNP's last).
-__global__ __launch_bounds__(256) void ts_flush(DevParams p, uint32_t par) {
-  __shared__ double s_fin[256];
+__global__ __launch_bounds__(512) void ts_flush(DevParams p, uint32_t par) {
+  __shared__ double s_fin[512];
   __shared__ double s_lam[2 * TSAMD_MAX_K];
   __shared__ double s_eb[2 * TSAMD_MAX_K];
   __shared__ double s_diff[2 * TSAMD_MAX_K];
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(256) void ts_flush(DevParams p, uint32_t par) {
     const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                           : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
                                            : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
-    finish_pending<256>(p, S, row_partial_sum<256>(rowsR, nrowsR, J), J, s_fin, s_lam, s_eb, s_diff, &s_flag);
+    finish_pending<512>(p, S, row_partial_sum<512>(rowsR, nrowsR, J), J, s_fin, s_lam, s_eb, s_diff, &s_flag);
     publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
   } else {
     carry_state(S, W, J);

@@ -81,4 +81,4 @@ def test_no_gpu_fails_loudly(ts):
     assert "no CPU path" in str(ei.value)
     # bad config is rejected before any device work
     with pytest.raises(ts.TsamdError):
-        ts.Engine(100, 10, 33)
+        ts.Engine(100, 10, 129)

@@ -94,7 +94,7 @@ def test_initial_state_matches_init_lambda(ts):
         assert rel_err(eng.get_elogtheta(), orc.elogtheta()) < 1e-12
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 6, 8, 12, 20, 32])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 6, 8, 12, 20, 32, 33, 40, 100, 128])
 def test_single_pass_known_answer(ts, k):
     """One pass of phi + lambda_t + epilogue (max_inner = 1): rel 1e-12."""
     n, l = 2500, 6
@@ -143,7 +143,8 @@ def test_hol_mode_suppresses_step(ts):
         assert eng.get_counts().max() == 2  # steps of loc 1 and loc 2 only
 
 
-@pytest.mark.parametrize("n,l,k", [(200, 40, 3), (1000, 64, 6), (5000, 48, 8), (3001, 32, 20), (70000, 24, 5), (2000, 16, 31)])
+@pytest.mark.parametrize("n,l,k", [(200, 40, 3), (1000, 64, 6), (5000, 48, 8), (3001, 32, 20), (70000, 24, 5), (2000, 16, 31),
+                                   (3000, 24, 48), (9001, 16, 70)])
 def test_trajectory_matches_oracle(ts, n, l, k):
     eng, orc, _ = make_pair(ts, n, l, k, 1000 + n)
     rng = np.random.default_rng(n)
@@ -257,7 +258,7 @@ def test_sharded_contexts_slice_columns(ts):
 
 def test_error_paths(ts):
     with pytest.raises(ts.TsamdError):
-        ts.Engine(100, 10, 33)  # K above compiled maximum
+        ts.Engine(100, 10, 129)  # K above compiled maximum
     with pytest.raises(ts.TsamdError):
         ts.Engine(0, 10, 3)
     with ts.Engine(100, 10, 3) as eng:
@@ -352,4 +353,29 @@ def test_full_size_invariants(ts):
             eb = eng.get_ebeta()
             assert eb.min() > 0 and eb.max() < 1
             outs.append((eng.get_lambda(), g1))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_wide_k_graph_replay_bitwise(ts):
+    """K above TSAMD_SPECIALIZED_K (run-time-K fallback kernels): graph replay == eager, and the
+    held-out likelihood matches the oracle."""
+    n, l, k = 2500, 32, 37
+    locs = np.random.default_rng(5).integers(0, l, size=21).astype(np.uint32)
+    outs = []
+    for flags in (0, ts.FLAG_NO_GRAPH):
+        eng, orc, _ = make_pair(ts, n, l, k, 66, flags=flags)
+        with eng:
+            eng.run_schedule(locs)
+            eng.synchronize()
+            outs.append((eng.get_lambda(), eng.get_gamma()))
+            if flags == 0:
+                for loc in locs:
+                    orc.snp_update(int(loc))
+                assert_state_close(eng, orc, 1e-9, "wide K")
+                hl = int(orc.heldout_locs()[0])
+                eng.snp_update(hl, 1)
+                orc.snp_update(hl, 1)
+                a, c = eng.heldout_loglik(hl)
+                b, c2 = orc.heldout_loglik(hl)
+                assert c == c2 and abs(a - b) <= 1e-10 * abs(b)
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
