@@ -461,17 +461,30 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
       sb0[k] = do_gamma ? uniform_f64(s_sb[2 * k]) : 0.0;
       sb1[k] = do_gamma ? uniform_f64(s_sb[2 * k + 1]) : 0.0;
     }
-    for (uint32_t i = i0; i < end; i += BLOCK) {
-      WT wv[KT];
+    // software pipeline: the next item's rows (weights, gamma, counters, column words) are
+    // requested before the current item's transcendental-heavy update starts
+    using CT = typename LN::C;
+    auto load_item = [&](uint32_t i, WT (&wv)[KT], WT (&gv)[KT], CT &cv, uint32_t &word, uint32_t &pword) {
       load_rows(i, wv);
-      const uint32_t word = col[i / kItemsPerWord];
-      double w[VEC][KT];
+      word = col[i / kItemsPerWord];
       if (do_gamma) {
-        WT gv[KT];
 #pragma unroll
         for (int k = 0; k < KT; ++k) gv[k] = reinterpret_cast<const WT *>(p.gam + (size_t)k * np)[i];
-        typename LN::C cv = reinterpret_cast<const typename LN::C *>(p.cnt)[i];
-        const uint32_t pcode = pcol[i / kItemsPerWord] >> (kCodeBits * (i % kItemsPerWord));
+        cv = reinterpret_cast<const CT *>(p.cnt)[i];
+        pword = pcol[i / kItemsPerWord];
+      }
+    };
+    WT wv[KT], gv[KT], wv_n[KT], gv_n[KT];
+    CT cv{}, cv_n{};
+    uint32_t word = 0, pword = 0, word_n = 0, pword_n = 0;
+    if (i0 < end) load_item(i0, wv, gv, cv, word, pword);
+    for (uint32_t i = i0; i < end; i += BLOCK) {
+      const uint32_t inext = (i + BLOCK < end) ? i + BLOCK : i;  // clamped: static load counts
+      load_item(inext, wv_n, gv_n, cv_n, word_n, pword_n);
+      __builtin_amdgcn_sched_barrier(0);
+      double w[VEC][KT];
+      if (do_gamma) {
+        const uint32_t pcode = pword >> (kCodeBits * (i % kItemsPerWord));
         unpack_rows(wv, w);
         double g[VEC][KT];
         unpack_rows(gv, g);
@@ -498,11 +511,20 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
           reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = LN::pack(tg);
           reinterpret_cast<WT *>(p.w + (size_t)k * np)[i] = LN::pack(tw);
         }
-        reinterpret_cast<typename LN::C *>(p.cnt)[i] = LN::pack_c(cn);
+        reinterpret_cast<CT *>(p.cnt)[i] = LN::pack_c(cn);
       } else {
         unpack_rows(wv, w);
       }
       accumulate(i, w, word);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        wv[k] = wv_n[k];
+        gv[k] = gv_n[k];
+      }
+      cv = cv_n;
+      word = word_n;
+      pword = pword_n;
     }
   }
 
