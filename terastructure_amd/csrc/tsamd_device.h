@@ -133,9 +133,11 @@ __device__ __forceinline__ void exp_digamma_parts(double x, double &A, double &r
     num = fma(num, xi, den);
     den *= xi;
   }
-  r = num / den;
+  // one division serves both r = num / den and 1 / z
   const double z = x + 10.0;
-  const double rz = 1.0 / z;
+  const double inv = 1.0 / (den * z);
+  r = num * z * inv;
+  const double rz = den * inv;
   const double f = rz * rz;
   double t = -1.0 / 12.0;
   t = fma(f, t, 691.0 / 32760.0);
