@@ -220,7 +220,7 @@ __device__ __forceinline__ void gamma_step_one(double (&g)[KT], const double (&w
   const double base = p.nodetau0 + (double)c;
   const double rho = (p.nodekappa == 0.5) ? 1.0 / sqrt(base) : pow(base, -p.nodekappa);
   c += 1u;
-  const double c0 = mom / s0, c1 = dad / s1;
+  const double c0 = mom * fast_rcp(s0), c1 = dad * fast_rcp(s1);
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
     const double e = c0 * (w[k] * sb0[k]) + c1 * (w[k] * sb1[k]);  // y*phi_mom + (2-y)*phi_dad
