@@ -70,7 +70,8 @@ SYMBOLS = {
 
 
 def lib_path():
-    return _build.LIB_PATH
+    """libtsamd.so of this tree (TSAMD_LIB overrides it: kernel-variant experiments, tools/variant.sh)."""
+    return os.environ.get("TSAMD_LIB") or _build.LIB_PATH
 
 
 def load():

@@ -130,23 +130,25 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return fma(r, e, r);
 }
 
-// exp(psi(x)) split as A * exp(-r): A = z * exp(u(z)), z = x + 10,
-// u = -1/(2z) - sum B2n/(2n z^2n) (|u| <= 0.051, so exp(u) is an 8th-degree Taylor
-// polynomial, relative error < 1e-17) and r = sum_{i<10} 1/(x+i) = P'(x)/P(x).
-// Lets the gamma step form w[k] = A_k * exp(r_min - r_k) -- exp(Elogtheta) up to a
+// exp(psi(x)) split as z * exp(a): z = x + 10, a = u(z) - r(x) with
+// u = -1/(2z) - sum B2n/(2n z^2n) (the asymptotic series of psi(z) - log z, |u| <= 0.051) and
+// r = sum_{i<10} 1/(x+i).  Pairing the terms i and 9-i gives r = (2x+9) * Q'(q)/Q(q) with
+// q = x(x+9) and Q(q) = prod_{i<5} (q + i(9-i)) = prod_{i<10} (x+i): a degree-5 recurrence
+// instead of a degree-10 one, and one reciprocal serves both r and 1/z.
+// Lets the gamma step form w[k] = z_k * exp(a_k - a_max) -- exp(Elogtheta) up to a
 // per-individual factor -- with one exp and no log per population.
-__device__ __forceinline__ void exp_digamma_parts(double x, double &A, double &r) {
-  double num = 0.0, den = 1.0;
+__device__ __forceinline__ void exp_digamma_split(double x, double &z, double &a) {
+  const double q = x * (x + 9.0);
+  double num = 1.0, den = q;  // i = 0: q + 0
 #pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const double xi = x + (double)i;
-    num = fma(num, xi, den);
-    den *= xi;
+  for (int i = 1; i < 5; ++i) {
+    const double qi = q + (double)(i * (9 - i));
+    num = fma(num, qi, den);
+    den *= qi;
   }
-  // one division serves both r = num / den and 1 / z
-  const double z = x + 10.0;
+  z = x + 10.0;
   const double inv = fast_rcp(den * z);
-  r = num * z * inv;
+  const double r = (fma(2.0, x, 9.0) * num) * (z * inv);
   const double rz = den * inv;
   const double f = rz * rz;
   double t = -1.0 / 12.0;
@@ -156,17 +158,31 @@ __device__ __forceinline__ void exp_digamma_parts(double x, double &A, double &r
   t = fma(f, t, -1.0 / 252.0);
   t = fma(f, t, 1.0 / 120.0);
   t = fma(f, t, -1.0 / 12.0);
-  const double u = fma(f, t, -0.5 * rz);
-  double e = 1.0 / 40320.0;
-  e = fma(u, e, 1.0 / 5040.0);
-  e = fma(u, e, 1.0 / 720.0);
-  e = fma(u, e, 1.0 / 120.0);
-  e = fma(u, e, 1.0 / 24.0);
-  e = fma(u, e, 1.0 / 6.0);
-  e = fma(u, e, 0.5);
-  e = fma(u, e, 1.0);
-  e = fma(u, e, 1.0);
-  A = z * e;
+  a = fma(f, t, -0.5 * rz) - r;
+}
+
+// exp(d) for d <= 0 (the a_k - a_max above): two-constant Cody-Waite reduction by ln 2, degree-13
+// Taylor polynomial on |r| <= ln(2)/2 (truncation 6e-18), v_ldexp for the scaling -- which also
+// flushes the far tail to 0 -- and none of the overflow / NaN selects of the library exp.
+__device__ __forceinline__ double exp_nonpos(double d) {
+  const double n = __builtin_rint(d * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, d);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);  // (v_cvt_i32_f64 saturates; 2^-huge flushes to 0)
 }
 
 // v from lane (lane ^ OFF).  OFF < 32: ds_swizzle bit mode (no address register, no

@@ -187,21 +187,21 @@ __device__ __forceinline__ void wait_peer_rows(const DevParams &p, uint32_t slot
   __syncthreads();
 }
 
-// w[k] = exp(psi(g[k])) * exp(r_min) = A_k * exp(r_min - r_k): Elogtheta exponentiated
+// w[k] = exp(psi(g[k])) * exp(-a_max) = z_k * exp(a_k - a_max): Elogtheta exponentiated
 // up to a per-individual constant, which cancels in phi (estimate_theta,
-// src/snpsamplinge.cc:721-740).  The largest-gamma population gets exp(0), so w never
+// src/snpsamplinge.cc:721-740).  The population with the largest a gets exp(0), so w never
 // underflows for all k at once.
 template <int KT>
 __device__ __forceinline__ void gamma_to_w(const double (&g)[KT], double (&w)[KT]) {
-  double A[KT], r[KT];
-  double rmin = 1.0e300;
+  double z[KT], a[KT];
+  double amax = -1.0e300;
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
-    exp_digamma_parts(g[k], A[k], r[k]);
-    rmin = fmin(rmin, r[k]);
+    exp_digamma_split(g[k], z[k], a[k]);
+    amax = fmax(amax, a[k]);
   }
 #pragma unroll
-  for (int k = 0; k < KT; ++k) w[k] = A[k] * exp(rmin - r[k]);
+  for (int k = 0; k < KT; ++k) w[k] = z[k] * exp_nonpos(a[k] - amax);
 }
 
 // SVI step for one individual (update_gamma + update_rho_indiv,
@@ -312,6 +312,12 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
   const uint32_t siters = S->iters, snrows = S->nrows;
   const uint32_t sched_len = ctl->sched_len;
+  // plain pass: the location is known as soon as the state is (it only changes in a first
+  // pass), so the first column word is requested now and arrives during the epilogue
+  uint32_t word_early = 0;
+  if (!FIRST && cnt)
+    word_early = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride)[item(0) / kItemsPerWord];
+  __builtin_amdgcn_sched_barrier(0);
   const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                         : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
                                          : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
@@ -399,8 +405,10 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
         s0 = fma(w[v][k], b0[k], s0);
         s1 = fma(w[v][k], b1[k], s1);
       }
-      c0[v] = mom / s0;
-      c1[v] = dad / s1;
+      // (the first pass is arithmetic-bound next to its gamma step: reciprocal + two Newton steps
+      // there, IEEE division in the bandwidth-bound plain pass)
+      c0[v] = FIRST ? mom * fast_rcp(s0) : mom / s0;
+      c1[v] = FIRST ? dad * fast_rcp(s1) : dad / s1;
     }
 #pragma unroll
     for (int k = 0; k < KT; ++k)
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     WT bufB[KT];
     uint32_t wordA = 0, wordB = 0;
     if (cnt) {
-      wordA = col[item(0) / kItemsPerWord];
+      wordA = word_early;
       uint32_t t = 0;
       while (true) {
         const uint32_t t1 = t + 1u;
@@ -496,10 +504,17 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
           bool ok;
           code_weights((pcode >> (2 * v)) & 3u, mom, dad, ok);
           if (ok) {
+#if !defined(TSAMD_ABL) || TSAMD_ABL == 1 || TSAMD_ABL == 3
             gamma_step_one<KT>(g[v], w[v], sb0, sb1, mom, dad, cn[v], p);
+#endif
+#if !defined(TSAMD_ABL) || TSAMD_ABL == 3
             gamma_to_w<KT>(g[v], w[v]);
+#endif
           }
         }
+#if defined(TSAMD_ABL) && TSAMD_ABL == 3
+        if (w[0][0] == 123.456)
+#endif
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
           double tg[VEC], tw[VEC];

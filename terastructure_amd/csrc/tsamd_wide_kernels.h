@@ -127,21 +127,21 @@ __global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t
       const double rho = (p.nodekappa == 0.5) ? 1.0 / sqrt(base) : pow(base, -p.nodekappa);
       p.cnt[i] = c + 1u;
       const double c0 = mom / s0, c1 = dad / s1;
-      double rmin = 1.0e300;
+      double amax = -1.0e300;
       for (uint32_t k = 0; k < K; ++k) {
         const double wk = p.w[(size_t)k * np + i];
         const double e = c0 * (wk * s_sb[2 * k]) + c1 * (wk * s_sb[2 * k + 1]);
         double g = p.gam[(size_t)k * np + i];
         g += rho * (p.alpha + p.gamma_scale * e - g);
         p.gam[(size_t)k * np + i] = g;
-        double A, r;
-        exp_digamma_parts(g, A, r);
-        rmin = fmin(rmin, r);
+        double z, a;
+        exp_digamma_split(g, z, a);
+        amax = fmax(amax, a);
       }
       for (uint32_t k = 0; k < K; ++k) {  // (own stores above: same thread, program order)
-        double A, r;
-        exp_digamma_parts(p.gam[(size_t)k * np + i], A, r);
-        p.w[(size_t)k * np + i] = A * exp(rmin - r);
+        double z, a;
+        exp_digamma_split(p.gam[(size_t)k * np + i], z, a);
+        p.w[(size_t)k * np + i] = z * exp_nonpos(a - amax);
       }
     }
   }
@@ -242,16 +242,16 @@ __global__ __launch_bounds__(256) void ts_refresh_w_wide(DevParams p) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= p.npad) return;
   const size_t np = p.npad;
-  double rmin = 1.0e300;
+  double amax = -1.0e300;
   for (uint32_t k = 0; k < p.K; ++k) {
-    double A, r;
-    exp_digamma_parts(p.gam[(size_t)k * np + i], A, r);
-    rmin = fmin(rmin, r);
+    double z, a;
+    exp_digamma_split(p.gam[(size_t)k * np + i], z, a);
+    amax = fmax(amax, a);
   }
   for (uint32_t k = 0; k < p.K; ++k) {
-    double A, r;
-    exp_digamma_parts(p.gam[(size_t)k * np + i], A, r);
-    p.w[(size_t)k * np + i] = A * exp(rmin - r);
+    double z, a;
+    exp_digamma_split(p.gam[(size_t)k * np + i], z, a);
+    p.w[(size_t)k * np + i] = z * exp_nonpos(a - amax);
   }
 }
 

@@ -31,7 +31,67 @@ __global__ __launch_bounds__(256) void rd(const double2 *__restrict__ a, size_t 
   if (acc == 123.456) out[0] = acc;
 }
 
-int main() {
+// read-modify-write of two k-major [8][n] arrays (the first pass' traffic: R w, R gam, W gam, W w)
+template <typename T>
+__global__ __launch_bounds__(256) void rw(T *__restrict__ w, T *__restrict__ g, size_t nitems, uint32_t chunk) {
+  const uint32_t begin = blockIdx.x * chunk;
+  const uint32_t end = min((size_t)begin + chunk, nitems);
+  for (uint32_t i = begin + threadIdx.x; i < end; i += 256) {
+    T a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a[k] = w[(size_t)k * nitems + i];
+      b[k] = g[(size_t)k * nitems + i];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if constexpr (sizeof(T) == 16) {
+        g[(size_t)k * nitems + i] = T{b[k].x + a[k].x, b[k].y + a[k].y};
+        w[(size_t)k * nitems + i] = T{b[k].x - a[k].x, b[k].y - a[k].y};
+      } else {
+        g[(size_t)k * nitems + i] = b[k] + a[k];
+        w[(size_t)k * nitems + i] = b[k] - a[k];
+      }
+    }
+  }
+}
+
+template <typename T>
+void probe_rw(const char *name) {
+  const size_t n = 1u << 20;  // individuals; 8 rows x 8 B x n = 64 MB per array
+  const size_t nitems = n * 8 / sizeof(T);
+  T *w, *g;
+  CK(hipMalloc(&w, n * 64)); CK(hipMalloc(&g, n * 64));
+  CK(hipMemset(w, 0, n * 64)); CK(hipMemset(g, 0, n * 64));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (uint32_t grid : {256u, 512u, 1024u, 2048u, 4096u}) {
+    uint32_t chunk = (nitems + grid - 1) / grid; chunk = (chunk + 255) / 256 * 256;
+    const uint32_t gr = (nitems + chunk - 1) / chunk;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(rw<T>, dim3(gr), dim3(256), 0, 0, w, g, nitems, chunk);
+    CK(hipEventRecord(e0, 0));
+    const int reps = 20;
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(rw<T>, dim3(gr), dim3(256), 0, 0, w, g, nitems, chunk);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("rw %s (R 128 MB + W 128 MB) grid %4u: %.2f us/launch  %.0f GB/s\n", name, gr, ms / reps * 1e3, 4.0 * n * 64 / (ms / reps * 1e-3) / 1e9);
+  }
+  // device-to-device copy of the same volume, for reference
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < 20; ++r) { CK(hipMemcpyAsync(w, g, n * 64, hipMemcpyDeviceToDevice, 0)); CK(hipMemcpyAsync(g, w, n * 64, hipMemcpyDeviceToDevice, 0)); }
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("hipMemcpy D2D 2 x 64 MB (R 128 MB + W 128 MB): %.2f us  %.0f GB/s\n", ms / 20 * 1e3, 4.0 * n * 64 / (ms / 20 * 1e-3) / 1e9);
+  CK(hipFree(w)); CK(hipFree(g));
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1 && argv[1][0] == 'w') {
+    probe_rw<double>("8-byte");
+    probe_rw<double2>("16-byte");
+    return 0;
+  }
   const size_t sizes_mb[] = {64, 256, 2048};
   for (size_t mb : sizes_mb) {
     const size_t bytes = mb << 20;
