@@ -50,12 +50,13 @@ struct RowSum {
     if (r >= R) return v;
 #pragma unroll
     for (int u = 0; u < 8; ++u) v += (r + (uint32_t)u * R < nrows) ? t[u] : 0.0;
-    for (uint32_t g0 = r + 8u * R; g0 < nrows; g0 += 8u * R) {
-      double s[8];
+    // (sharded peer-to-peer: world x grid rows in uncached memory -- keep many loads in flight)
+    for (uint32_t g0 = r + 8u * R; g0 < nrows; g0 += 16u * R) {
+      double s[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s[u] = rows[(size_t)min(g0 + (uint32_t)u * R, nrows - 1u) * J + j];
+      for (int u = 0; u < 16; ++u) s[u] = rows[(size_t)min(g0 + (uint32_t)u * R, nrows - 1u) * J + j];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v += (g0 + (uint32_t)u * R < nrows) ? s[u] : 0.0;
+      for (int u = 0; u < 16; ++u) v += (g0 + (uint32_t)u * R < nrows) ? s[u] : 0.0;
     }
     return v;
   }
