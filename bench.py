@@ -46,46 +46,52 @@ def parse():
     return ap.parse_args()
 
 
-def choose_exchange(ts, dist, rank, world, local_rank, k):
-    """Per-pass exchange of the 2K lambda statistics: direct peer-to-peer stores over xGMI
-    when a small self-test reproduces the RCCL all-reduce result on this node, else RCCL.
-    TSAMD_EXCHANGE=rccl|p2p forces one."""
+def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_shard):
+    """Per-pass exchange of the 2K lambda statistics: direct peer-to-peer stores over xGMI or
+    the RCCL all-reduce.  Both are run on this node on the benchmark's own shards (a few SNP
+    columns, a short schedule): peer-to-peer is used when it reproduces the RCCL result and is
+    not slower.  TSAMD_EXCHANGE=rccl|p2p forces one."""
     import torch
 
     from terastructure_amd import dist as tdist
 
     forced = os.environ.get("TSAMD_EXCHANGE", "auto").lower()
     if forced in ("rccl", "p2p"):
-        return forced
-    n, l = 8192 * world, 8
-    rng = np.random.default_rng(7)
-    theta = rng.dirichlet(np.full(k, 0.2), size=n)
-    beta = rng.uniform(0.05, 0.95, size=(l, k))
-    gamma = rng.gamma(100.0, 0.01, size=(n, k))
-    locs = np.array([3, 1, 3, 7, 0, 5], dtype=np.uint32)
-    out = {}
+        return forced, {}
+    l = 32
+    beta = np.random.default_rng(7).uniform(0.05, 0.95, size=(l, k))
+    locs = np.random.default_rng(8).integers(0, l, size=260).astype(np.uint32)
+    locs[:6] = [3, 1, 3, 7, 0, 5]
+    out, rate = {}, {}
     for mode in ("rccl", "p2p"):
         out[mode] = None
         e = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
         try:
-            b, c = e.shard_begin, e.shard_count
-            e.synth_genotypes(theta[b:b + c], beta, seed=11)
-            e.set_gamma(gamma[b:b + c])
+            e.synth_genotypes(theta_shard, beta, seed=11)
+            e.set_gamma(gamma_shard)
             try:
                 (tdist.bootstrap_p2p if mode == "p2p" else tdist.bootstrap_comm)(e, dist)
             except Exception as exc:  # noqa: BLE001 -- raised on every rank together
                 if rank == 0:
                     print(f"[bench] exchange self-test, {mode}: {exc}", file=sys.stderr, flush=True)
                 continue
-            res, err = None, None
+            res, err, dt = None, None, 0.0
             try:
-                e.run_schedule(locs)
+                e.run_schedule(locs[:60])
                 e.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                e.run_schedule(locs[60:])
+                e.synchronize()
+                dt = time.perf_counter() - t0
                 res = (e.get_lambda(), e.get_gamma())
             except Exception as exc:  # noqa: BLE001
                 err = exc
             if tdist.all_ok(err is None, dist):
                 out[mode] = res
+                tt = torch.tensor([dt], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                rate[mode] = round((len(locs) - 60) / float(tt.item()), 1)
             elif rank == 0:
                 print(f"[bench] exchange self-test, {mode}: run failed ({err})", file=sys.stderr, flush=True)
         finally:
@@ -95,7 +101,13 @@ def choose_exchange(ts, dist, rank, world, local_rank, k):
     ok = out["p2p"] is not None
     if ok and out["rccl"] is not None:
         ok = all(np.allclose(a, b_, rtol=1e-10, atol=0) for a, b_ in zip(out["rccl"], out["p2p"]))
-    return "p2p" if tdist.all_ok(ok, dist) else "rccl"
+    ok = tdist.all_ok(ok, dist)
+    if ok and out["rccl"] is not None and rate["p2p"] < rate["rccl"]:  # (rates are identical on every rank)
+        ok = False
+    if rank == 0:
+        print(f"[bench] exchange self-test: updates/s {rate}, p2p valid {out['p2p'] is not None} -> "
+              f"{'p2p' if ok else 'rccl'}", file=sys.stderr, flush=True)
+    return ("p2p" if ok else "rccl"), rate
 
 
 def main():
@@ -138,9 +150,13 @@ def main():
         l = int(t.item())
 
     t_setup = time.time()
-    exchange = "none"
+    # synthetic PSD data (SURVEY 8d): theta ~ Dir(0.2), beta ~ U(0.05, 0.95), y ~ Bin(2, theta.beta)
+    rng = np.random.default_rng(args.seed)
+    theta = rng.dirichlet(np.full(k, 0.2), size=n)[sb:sb + sc]
+    gamma0 = np.random.default_rng(args.seed + 2).gamma(100.0, 0.01, size=(n, k))[sb:sb + sc]
+    exchange, exchange_rates = "none", {}
     if world > 1:
-        exchange = choose_exchange(ts, dist, rank, world, local_rank, k)
+        exchange, exchange_rates = choose_exchange(ts, dist, rank, world, local_rank, n, k, theta, gamma0)
     eng = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
     if world > 1:
         from terastructure_amd import dist as tdist
@@ -150,16 +166,13 @@ def main():
         else:
             tdist.bootstrap_comm(eng, dist)
 
-    # synthetic PSD data (SURVEY 8d): theta ~ Dir(0.2), beta ~ U(0.05, 0.95), y ~ Bin(2, theta.beta)
-    rng = np.random.default_rng(args.seed)
-    theta = rng.dirichlet(np.full(k, 0.2), size=n)[sb:sb + sc]
     chunk = 1 << 17
     brng = np.random.default_rng(args.seed + 1)
     for l0 in range(0, l, chunk):
         beta = brng.uniform(0.05, 0.95, size=(min(chunk, l - l0), k))
         eng.synth_genotypes(theta, beta, first_loc=l0, seed=args.seed)
-    eng.set_gamma(np.random.default_rng(args.seed + 2).gamma(100.0, 0.01, size=(n, k))[sb:sb + sc])
-    del theta
+    eng.set_gamma(gamma0)
+    del theta, gamma0
     setup_s = time.time() - t_setup
 
     locs = np.random.default_rng(args.seed + 3).integers(0, l, size=args.warmup + args.steps).astype(np.uint32)
@@ -259,7 +272,8 @@ def main():
             "config": {"workload": f"synthetic PSD N={n} individuals x L={l} SNPs, K={k}, 2-bit genotypes "
                                    f"HBM-resident, individuals sharded over {world} GPU(s)",
                        "n": n, "l": l, "k": k, "l_requested": args.l,
-                       "parallelism": f"individual-shard x{world}", "exchange": exchange},
+                       "parallelism": f"individual-shard x{world}", "exchange": exchange,
+                       "exchange_selftest_updates_per_s": exchange_rates},
             "mean_inner_passes": round(mean_passes, 3),
             "nk_pass_per_s": round(value * mean_passes * n * k, 1),
             "update_algorithmic_bytes": alg_update,
