@@ -50,13 +50,12 @@ struct RowSum {
     if (r >= R) return v;
 #pragma unroll
     for (int u = 0; u < 8; ++u) v += (r + (uint32_t)u * R < nrows) ? t[u] : 0.0;
-    // (sharded peer-to-peer: world x grid rows in uncached memory -- keep many loads in flight)
-    for (uint32_t g0 = r + 8u * R; g0 < nrows; g0 += 16u * R) {
-      double s[16];
+    for (uint32_t g0 = r + 8u * R; g0 < nrows; g0 += 8u * R) {
+      double s[8];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) s[u] = rows[(size_t)min(g0 + (uint32_t)u * R, nrows - 1u) * J + j];
+      for (int u = 0; u < 8; ++u) s[u] = rows[(size_t)min(g0 + (uint32_t)u * R, nrows - 1u) * J + j];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v += (g0 + (uint32_t)u * R < nrows) ? s[u] : 0.0;
+      for (int u = 0; u < 8; ++u) v += (g0 + (uint32_t)u * R < nrows) ? s[u] : 0.0;
     }
     return v;
   }
@@ -174,18 +173,45 @@ __device__ __forceinline__ void carry_state(const State *S, State *W, uint32_t J
 // Called by all threads of a workgroup.
 __device__ __forceinline__ void wait_peer_rows(const DevParams &p, uint32_t slot, unsigned long long epoch,
                                                uint32_t nflags) {
-  for (uint32_t t = threadIdx.x; t < nflags; t += blockDim.x) {
-    const unsigned long long *flag = &p.xchg->seq[slot][t];
-    const unsigned long long t0 = wall_clock64();  // 100 MHz
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+  // a thread watches up to four flags at once (the flags are uncached: one poll is a trip to
+  // memory, so the polls of one thread must not queue behind each other)
+  const unsigned long long *seq = p.xchg->seq[slot];
+  for (uint32_t t0 = threadIdx.x; t0 < nflags; t0 += 4u * blockDim.x) {
+    const unsigned long long start = wall_clock64();  // 100 MHz
+    while (true) {
+      unsigned long long f[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t t = t0 + (uint32_t)u * blockDim.x;
+        f[u] = __hip_atomic_load(&seq[t < nflags ? t : t0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (f[0] >= epoch && f[1] >= epoch && f[2] >= epoch && f[3] >= epoch) break;
       __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > 300000000ull) {  // 3 s: a peer died; report instead of hanging
+      if (wall_clock64() - start > 300000000ull) {  // 3 s: a peer died; report instead of hanging
         __hip_atomic_store(&p.xchg->error, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
     }
   }
   __syncthreads();
+}
+
+// Partial row sum over the exchange buffer: the same fixed order as RowSum (thread (r, j) adds
+// rows r, r+R, ...) with up to 32 loads in flight per thread -- the buffer is uncached, so
+// every batch is a full trip to memory.
+template <int BLOCK>
+__device__ __forceinline__ double row_partial_sum_xchg(const double *rows, uint32_t nrows, uint32_t J) {
+  const uint32_t R = BLOCK / J, j = threadIdx.x % J, r = threadIdx.x / J;
+  double v = 0.0;
+  if (r >= R || nrows == 0u) return v;
+  for (uint32_t g0 = r; g0 < nrows; g0 += 32u * R) {
+    double s[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) s[u] = rows[(size_t)min(g0 + (uint32_t)u * R, nrows - 1u) * J + j];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v += (g0 + (uint32_t)u * R < nrows) ? s[u] : 0.0;
+  }
+  return v;
 }
 
 // w[k] = exp(psi(g[k])) * exp(-a_max) = z_k * exp(a_k - a_max): Elogtheta exponentiated
@@ -328,7 +354,10 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const bool pending = svalid != 0u && sdone == 0u;
   if (pending && p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
   double vrow = 0.0;
-  if (pending) vrow = (local_rows && nrowsR == nrows_hint) ? rowsum.finish() : row_partial_sum<BLOCK>(rowsR, nrowsR, J);
+  if (pending)
+    vrow = (local_rows && nrowsR == nrows_hint) ? rowsum.finish()
+           : p.xchg_world                       ? row_partial_sum_xchg<BLOCK>(rowsR, nrowsR, J)
+                                                : row_partial_sum<BLOCK>(rowsR, nrowsR, J);
   uint32_t loc, hol, idx, iters;
   bool do_gamma = false;
   uint32_t prev_loc = 0;
@@ -622,7 +651,8 @@ __global__ __launch_bounds__(512) void ts_flush(DevParams p, uint32_t par) {
     const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                           : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
                                            : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
-    finish_pending<512>(p, S, row_partial_sum<512>(rowsR, nrowsR, J), J, s_fin, s_lam, s_eb, s_diff, &s_flag);
+    const double vrow = p.xchg_world ? row_partial_sum_xchg<512>(rowsR, nrowsR, J) : row_partial_sum<512>(rowsR, nrowsR, J);
+    finish_pending<512>(p, S, vrow, J, s_fin, s_lam, s_eb, s_diff, &s_flag);
     publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
   } else {
     carry_state(S, W, J);
