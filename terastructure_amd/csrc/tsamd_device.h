@@ -161,7 +161,8 @@ __device__ __forceinline__ void exp_digamma_split(double x, double &z, double &a
   a = fma(f, t, -0.5 * rz) - r;
 }
 
-// exp(d) for d <= 0 (the a_k - a_max above): two-constant Cody-Waite reduction by ln 2, degree-13
+// exp(d) for d <= 0 (the a_k - a_max above; also fine for moderate d > 0 -- nothing here
+// depends on the sign, only overflow is not handled): two-constant Cody-Waite reduction by ln 2, degree-13
 // Taylor polynomial on |r| <= ln(2)/2 (truncation 6e-18), v_ldexp for the scaling -- which also
 // flushes the far tail to 0 -- and none of the overflow / NaN selects of the library exp.
 __device__ __forceinline__ double exp_nonpos(double d) {
@@ -185,29 +186,49 @@ __device__ __forceinline__ double exp_nonpos(double d) {
   return __builtin_amdgcn_ldexp(p, (int)n);  // (v_cvt_i32_f64 saturates; 2^-huge flushes to 0)
 }
 
-// v from lane (lane ^ OFF).  OFF < 32: ds_swizzle bit mode (no address register, no
-// memory access); OFF == 32: ds_bpermute.
+// Cross-lane moves of the wave fold, all on the vector ALU (no trip through the LDS pipe):
+//  * pair_add<32|16>(a, b): v_permlane32_swap / v_permlane16_swap (gfx950) exchange the upper
+//    half-wave (odd 16-lane rows) of a with the lower half-wave (even rows) of b, after which
+//    a' + b' is, in every lane, "the operand this lane keeps + the same operand of its partner
+//    lane (lane ^ 32 / lane ^ 16)": lower lanes keep a, upper lanes keep b.
+//  * partner<8|4|2|1>(v): DPP row_mirror / row_half_mirror / quad_perm: the value of the lane's
+//    partner at that level (lane ^ 15, ^ 7, ^ 2, ^ 1 -- any pairing across the level's bit works
+//    for a halving butterfly).
 template <int OFF>
-__device__ __forceinline__ double xor_lane(double v) {
-  const unsigned long long u = __double_as_longlong(v);
-  int lo = (int)(uint32_t)u, hi = (int)(uint32_t)(u >> 32);
-  if constexpr (OFF < 32) {
-    constexpr int pattern = (OFF << 10) | 0x1f;  // and_mask 0x1f, or_mask 0, xor_mask OFF
-    lo = __builtin_amdgcn_ds_swizzle(lo, pattern);
-    hi = __builtin_amdgcn_ds_swizzle(hi, pattern);
+__device__ __forceinline__ double pair_add(double a, double b) {
+  static_assert(OFF == 32 || OFF == 16, "half-wave / row swaps only");
+  const unsigned long long ua = __double_as_longlong(a), ub = __double_as_longlong(b);
+  unsigned a_lo, a_hi, b_lo, b_hi;
+  if constexpr (OFF == 32) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    a_lo = lo[0], b_lo = lo[1], a_hi = hi[0], b_hi = hi[1];
   } else {
-    const int addr = (int)((__lane_id() ^ 32u) << 2);
-    lo = __builtin_amdgcn_ds_bpermute(addr, lo);
-    hi = __builtin_amdgcn_ds_bpermute(addr, hi);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    a_lo = lo[0], b_lo = lo[1], a_hi = hi[0], b_hi = hi[1];
   }
+  return __longlong_as_double(((unsigned long long)a_hi << 32) | a_lo) +
+         __longlong_as_double(((unsigned long long)b_hi << 32) | b_lo);
+}
+
+template <int OFF>
+__device__ __forceinline__ double partner(double v) {
+  static_assert(OFF == 8 || OFF == 4 || OFF == 2 || OFF == 1, "DPP levels only");
+  constexpr int ctrl = OFF == 8 ? 0x140 /* row_mirror */ : OFF == 4 ? 0x141 /* row_half_mirror */
+                       : OFF == 2 ? 0x4E /* quad_perm [2,3,0,1] */ : 0xB1 /* quad_perm [1,0,3,2] */;
+  const unsigned long long u = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, ctrl, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), ctrl, 0xf, 0xf, false);
   return __longlong_as_double(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
 // Sum NV per-lane values across the 64 lanes of a wave with a halving butterfly: at
 // each step a lane keeps half of its values and trades the other half with its partner,
-// so the traffic is NV + NV/2 + ... instead of 6 * NV shuffles.  NV is padded to a power
+// so the traffic is NV + NV/2 + ... instead of 6 * NV cross-lane moves.  NV is padded to a power
 // of two P <= 64.  On return v[0] of lane l holds the wave total of value
-// wave_sum_slot<NV>(l) (all lanes sharing that slot hold the same bits).  Fixed order.
+// slot(l).  Fixed order; lanes sharing a slot add in different association orders, so the
+// caller takes the value of the lowest such lane.
 template <int NV>
 struct WaveFold {
   static constexpr int P = NV <= 1 ? 1 : NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : NV <= 32 ? 32 : 64;
@@ -228,16 +249,24 @@ struct WaveFold {
       constexpr int off = 32 >> S;
       if constexpr (H > 1) {
         constexpr int h = H / 2;
-        const bool up = (lane & (uint32_t)off) != 0u;  // upper partner keeps the upper half
+        if constexpr (off >= 16) {
 #pragma unroll
-        for (int i = 0; i < h; ++i) {
-          const double keep = up ? v[i + h] : v[i];
-          const double send = up ? v[i] : v[i + h];
-          v[i] = keep + xor_lane<off>(send);
+          for (int i = 0; i < h; ++i) v[i] = pair_add<off>(v[i], v[i + h]);
+        } else {
+          const bool up = (lane & (uint32_t)off) != 0u;  // upper partner keeps the upper half
+#pragma unroll
+          for (int i = 0; i < h; ++i) {
+            const double keep = up ? v[i + h] : v[i];
+            const double send = up ? v[i] : v[i + h];
+            v[i] = keep + partner<off>(send);
+          }
         }
         step<S + 1, h>(v, lane);
       } else {
-        v[0] += xor_lane<off>(v[0]);
+        if constexpr (off >= 16)
+          v[0] = pair_add<off>(v[0], v[0]);
+        else
+          v[0] += partner<off>(v[0]);
         step<S + 1, 1>(v, lane);
       }
     }

@@ -68,55 +68,57 @@ __device__ __forceinline__ double row_partial_sum(const double *rows, uint32_t n
   return rs.finish();
 }
 
-// Finish the pending pass described by S from the per-thread partial row sums v (see
+// Finish the pending pass described by `in` (load_pending: issued early, with the other state
+// loads -- a load placed after the first barrier here would be a full memory latency on the
+// critical path of every pass) from the per-thread partial row sums v (see
 // RowSum; then r = 0..R-1): lambda_t[j] = eb_used[j] * sum_rows, then update_lambda +
 // estimate_beta + convergence test (src/snpsamplinge.cc:356-364, :267-296; abs_mean
 // src/matrix.hh:885-893).  Called by ALL threads of a workgroup.
 // Outputs in LDS: s_lam = new lambda[loc], s_eb = new exp(Elogbeta[loc]).
 // Returns (uniformly) whether the SNP is complete (converged or max_inner passes run).
+struct PendingIn {  // what the epilogue needs from the previous launch's State, loaded by the
+  double eb_used;   // caller together with the rest of the state (for j = tid < J): the
+  double lam_old;   // exp(Elogbeta) the pass used, lambda before it, passes run so far
+  uint32_t iters;
+};
+__device__ __forceinline__ PendingIn load_pending(const State *S, uint32_t J) {
+  PendingIn in;
+  const uint32_t tid = threadIdx.x;
+  in.eb_used = S->eb[tid < J ? tid : 0u];
+  in.lam_old = S->lam[tid < J ? tid : 0u];
+  in.iters = S->iters;
+  return in;
+}
 template <int BLOCK>
-__device__ __forceinline__ bool finish_pending(const DevParams &p, const State *S, double v, uint32_t J,
-                                               double *s_fin, double *s_lam, double *s_eb, double *s_diff,
-                                               uint32_t *s_flag) {
+__device__ __forceinline__ bool finish_pending(const DevParams &p, const PendingIn &in, double v, uint32_t J,
+                                               double *s_fin, double *s_lam, double *s_eb, double *s_diff) {
   const uint32_t tid = threadIdx.x;
   const uint32_t R = BLOCK / J;
   s_fin[tid] = v;
   __syncthreads();
-  double nw = 0.0;
   if (tid < J) {
     double lt = 0.0;
     for (uint32_t rr = 0; rr < R; ++rr) lt += s_fin[rr * J + tid];
-    lt *= S->eb[tid];  // the b[k,t] factored out of the accumulation
-    const double old = S->lam[tid];
-    nw = ((tid & 1u) ? p.eta1 : p.eta0) + lt;
+    lt *= in.eb_used;  // the b[k,t] factored out of the accumulation
+    const double nw = ((tid & 1u) ? p.eta1 : p.eta0) + lt;
+    // exp(Elogbeta_kt) = exp(psi(lambda_kt) - psi(lambda_k0 + lambda_k1)) without a log: both
+    // digammas in the split form z * exp(a) (tsamd_device.h), side by side in one instruction
+    // stream; the pair sum comes from the neighbouring lane (t = 0/1 are adjacent threads)
+    const double pair = nw + partner<1>(nw);
+    double z1, a1, z2, a2;
+    exp_digamma_split(nw, z1, a1);
+    exp_digamma_split(pair, z2, a2);
     s_lam[tid] = nw;
-    s_diff[tid] = fabs(nw - old);
+    s_eb[tid] = (z1 * fast_rcp(z2)) * exp_nonpos(a1 - a2);
+    s_diff[tid] = fabs(nw - in.lam_old);
   }
   __syncthreads();
-  // psi(lambda_kt) on threads [0, J) and psi(lambda_k0 + lambda_k1) on threads [J, J + K) in
-  // ONE instruction stream: the two digamma chains of estimate_beta run side by side
-  double psi_own;
-  if (J + J / 2 <= (uint32_t)BLOCK) {
-    const bool is_sum = tid >= J && tid < J + J / 2;
-    double x = nw;
-    if (is_sum) x = s_lam[2 * (tid - J)] + s_lam[2 * (tid - J) + 1];
-    const double psi_x = (tid < J + J / 2) ? digamma(x) : 0.0;
-    if (is_sum) s_fin[tid - J] = psi_x;
-    psi_own = psi_x;
-  } else {  // wide K in a small workgroup: one chain after the other
-    psi_own = (tid < J) ? digamma(nw) : 0.0;
-    if (tid < J / 2) s_fin[tid] = digamma(s_lam[2 * tid] + s_lam[2 * tid + 1]);
-  }
-  if (tid == 0) {
-    double d = 0.0;
-    for (uint32_t jj = 0; jj < J; ++jj) d += s_diff[jj];
-    d /= (double)J;
-    *s_flag = (d < p.thresh || S->iters >= p.max_inner) ? 1u : 0u;
-  }
-  __syncthreads();
-  if (tid < J) s_eb[tid] = exp(psi_own - s_fin[tid >> 1]);
-  __syncthreads();
-  return *s_flag != 0u;
+  // every thread takes the convergence decision itself (saves a barrier): mean |dlambda| in
+  // the reference's order j = 0 .. J-1
+  double d = 0.0;
+  for (uint32_t jj = 0; jj < J; ++jj) d += s_diff[jj];
+  d /= (double)J;
+  return d < p.thresh || in.iters >= p.max_inner;
 }
 
 // workgroup 0 publishes the completed SNP: final lambda / exp(Elogbeta) into the global
@@ -301,11 +303,17 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   __shared__ double s_diff[J];
   __shared__ double s_red[kWaves][J];
   __shared__ double s_fin[BLOCK];
-  __shared__ uint32_t s_flag;
 
   Ctl *ctl = p.ctl;
   const State *S = &ctl->st[par ^ 1u];
   State *W = &ctl->st[par];
+#ifdef TSAMD_TRACE
+  unsigned long long tr[6];
+  tr[0] = wall_clock64();
+#define TSAMD_TR(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr[k] = wall_clock64(); } while (0)
+#else
+#define TSAMD_TR(k) do { } while (0)
+#endif
   const uint32_t tid = threadIdx.x;
   const size_t np = p.npad;
   const uint32_t nitems = p.npad / VEC;
@@ -339,6 +347,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
   const uint32_t siters = S->iters, snrows = S->nrows;
   const uint32_t sched_len = ctl->sched_len;
+  const PendingIn pin = load_pending(S, J);
   // plain pass: the location is known as soon as the state is (it only changes in a first
   // pass), so the first column word is requested now and arrives during the epilogue
   uint32_t word_early = 0;
@@ -351,6 +360,8 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t nrowsR = p.xchg_world ? p.xchg_world * snrows : p.rows_from_lt ? 1u : snrows;
   double *rowsW = p.partials + (size_t)par * kMaxGrid * J;
 
+  if (sidx == 12345678u) return;  // (forces the state load to complete before the stamp)
+  TSAMD_TR(1);
   const bool pending = svalid != 0u && sdone == 0u;
   if (pending && p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
   double vrow = 0.0;
@@ -358,6 +369,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     vrow = (local_rows && nrowsR == nrows_hint) ? rowsum.finish()
            : p.xchg_world                       ? row_partial_sum_xchg<BLOCK>(rowsR, nrowsR, J)
                                                 : row_partial_sum<BLOCK>(rowsR, nrowsR, J);
+  TSAMD_TR(2);
   uint32_t loc, hol, idx, iters;
   bool do_gamma = false;
   uint32_t prev_loc = 0;
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
       if (blockIdx.x == 0) carry_state(S, W, J);
       return;
     }
-    const bool complete = finish_pending<BLOCK>(p, S, vrow, J, s_fin, s_lam, s_eb, s_diff, &s_flag);
+    const bool complete = finish_pending<BLOCK>(p, pin, vrow, J, s_fin, s_lam, s_eb, s_diff);
     if (complete) {
       if (blockIdx.x == 0) publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
       return;
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     iters = siters + 1u;
   } else {
     idx = sidx + 1u;  // 0xffffffff + 1 = 0: first SNP of the schedule
-    if (pending) finish_pending<BLOCK>(p, S, vrow, J, s_fin, s_plam, s_peb, s_diff, &s_flag);
+    if (pending) finish_pending<BLOCK>(p, pin, vrow, J, s_fin, s_plam, s_peb, s_diff);
     if (idx >= sched_len) {  // schedule exhausted: complete what is pending, carry state
       if (blockIdx.x == 0) {
         if (pending)
@@ -420,6 +432,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t *col = reinterpret_cast<const uint32_t *>(p.bed + (size_t)loc * p.colstride);
   const uint32_t *pcol = reinterpret_cast<const uint32_t *>(p.bed + (size_t)prev_loc * p.colstride);
 
+  TSAMD_TR(3);
   // ---- main sweep -------------------------------------------------------------------
   auto accumulate = [&](uint32_t i, const double (&w)[VEC][KT], uint32_t word) {
     const uint32_t code = word >> (kCodeBits * (i % kItemsPerWord));
@@ -573,6 +586,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     }
   }
 
+  TSAMD_TR(4);
   // workgroup reduction, fixed order: lanes (halving butterfly) -> waves (0..kWaves-1)
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   {
@@ -630,6 +644,12 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
       W->epoch = S->epoch + 1ull;
     }
   }
+#ifdef TSAMD_TRACE
+  TSAMD_TR(5);
+  if (blockIdx.x == 0 && tid == 0 && idx >= 40u && idx < 44u)
+    printf("trace %s idx %u it %u: state %llu rows %llu epilogue %llu sweep %llu tail %llu (x10 ns)\n", FIRST ? "first" : "plain",
+           idx, iters, tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3], tr[5] - tr[4]);
+#endif
 }
 
 #ifdef TSAMD_MAIN_TU  // K-independent kernels: compiled into tsamd.hip only
@@ -640,11 +660,11 @@ __global__ __launch_bounds__(512) void ts_flush(DevParams p, uint32_t par) {
   __shared__ double s_lam[2 * TSAMD_MAX_K];
   __shared__ double s_eb[2 * TSAMD_MAX_K];
   __shared__ double s_diff[2 * TSAMD_MAX_K];
-  __shared__ uint32_t s_flag;
   Ctl *ctl = p.ctl;
   const State *S = &ctl->st[par ^ 1u];
   State *W = &ctl->st[par];
   const uint32_t J = 2 * p.K;
+  const PendingIn pin = load_pending(S, J);
   if (S->valid != 0u && S->done == 0u) {
     const uint32_t nrowsR = p.xchg_world ? p.xchg_world * S->nrows : p.rows_from_lt ? 1u : S->nrows;
     if (p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
@@ -652,7 +672,7 @@ __global__ __launch_bounds__(512) void ts_flush(DevParams p, uint32_t par) {
                           : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
                                            : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
     const double vrow = p.xchg_world ? row_partial_sum_xchg<512>(rowsR, nrowsR, J) : row_partial_sum<512>(rowsR, nrowsR, J);
-    finish_pending<512>(p, S, vrow, J, s_fin, s_lam, s_eb, s_diff, &s_flag);
+    finish_pending<512>(p, pin, vrow, J, s_fin, s_lam, s_eb, s_diff);
     publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
   } else {
     carry_state(S, W, J);

@@ -27,7 +27,6 @@ __global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t
   __shared__ double s_diff[kWideJ];
   __shared__ double s_red[kWaves][kWideJ];
   __shared__ double s_fin[BLOCK];
-  __shared__ uint32_t s_flag;
 
   Ctl *ctl = p.ctl;
   const State *S = &ctl->st[par ^ 1u];
@@ -43,6 +42,7 @@ __global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t
   const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
   const uint32_t siters = S->iters, snrows = S->nrows;
   const uint32_t sched_len = ctl->sched_len;
+  const PendingIn pin = load_pending(S, J);
   const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                         : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
                                          : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t
       if (blockIdx.x == 0) carry_state(S, W, J);
       return;
     }
-    const bool complete = finish_pending<BLOCK>(p, S, vrow, J, s_fin, s_lam, s_eb, s_diff, &s_flag);
+    const bool complete = finish_pending<BLOCK>(p, pin, vrow, J, s_fin, s_lam, s_eb, s_diff);
     if (complete) {
       if (blockIdx.x == 0) publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
       return;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t
     iters = siters + 1u;
   } else {
     idx = sidx + 1u;
-    if (pending) finish_pending<BLOCK>(p, S, vrow, J, s_fin, s_plam, s_peb, s_diff, &s_flag);
+    if (pending) finish_pending<BLOCK>(p, pin, vrow, J, s_fin, s_plam, s_peb, s_diff);
     if (idx >= sched_len) {
       if (blockIdx.x == 0) {
         if (pending)
