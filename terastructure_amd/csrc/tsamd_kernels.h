@@ -360,7 +360,9 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t nrowsR = p.xchg_world ? p.xchg_world * snrows : p.rows_from_lt ? 1u : snrows;
   double *rowsW = p.partials + (size_t)par * kMaxGrid * J;
 
+#ifdef TSAMD_TRACE
   if (sidx == 12345678u) return;  // (forces the state load to complete before the stamp)
+#endif
   TSAMD_TR(1);
   const bool pending = svalid != 0u && sdone == 0u;
   if (pending && p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
