@@ -41,9 +41,28 @@ def parse():
     ap.add_argument("--pops", "--k", dest="k", type=int, default=8)
     ap.add_argument("--seed", type=int, default=20240607)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all usable host cores (affinity and cgroup quota)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event pass-kernel timing leg")
     return ap.parse_args()
+
+
+def usable_cores():
+    """Host cores this process may really use: the smaller of the affinity mask and the
+    cgroup CPU quota (a container can see 256 CPUs and be entitled to 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_shard):
@@ -239,7 +258,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         import oracle_py as op
 
-        cores = args.cpu_threads or (os.cpu_count() or 1)
+        cores = args.cpu_threads or usable_cores()
         ls = 8  # sample columns; per-update cost does not depend on L
         orc = op.Oracle(n, ls, k, nthreads=cores, gamma_scale=float(l))
         sample = np.stack([eng.download_bed(int(j)) for j in range(ls)])
@@ -258,7 +277,8 @@ def main():
                "kind": "port",
                "sample": f"{done} updates (10 passes + gamma step each) at N={n}, K={k} on {ls} of the "
                          f"benchmark's own columns, oracle/ts_oracle.c with {cores} OpenMP threads "
-                         f"in the reference's work partition"}
+                         f"in the reference's work partition (host shows {os.cpu_count()} CPUs, "
+                         f"{cores} usable under its affinity mask / cgroup quota)"}
         orc.close()
 
     if rank == 0:
