@@ -755,11 +755,20 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   // of kGraphSnps SNPs is replayed as often as needed; kernels past the end of the
   // schedule only carry the state forward.  (kGraphSnps is even, so a replay keeps the
   // launch parity.)
-  const bool use_graph =
-      !(c->cfg.flags & TSAMD_FLAG_NO_GRAPH) && (!c->comm || c->p2p) && !c->prof && n >= kGraphSnps;
+  // (RCCL all-reduce inside the captured sequence: opt-in, TSAMD_RCCL_GRAPH=1 on every rank)
+  const bool comm_graph = c->comm && !c->p2p && env_u32("TSAMD_RCCL_GRAPH", 0) != 0u;
+  const bool use_graph = !(c->cfg.flags & TSAMD_FLAG_NO_GRAPH) && (!c->comm || c->p2p || comm_graph) && !c->prof &&
+                         n >= kGraphSnps;
   if (use_graph) {
-    if (!c->graph_exec)
+    if (!c->graph_exec) {
+      if (comm_graph) {  // first collective outside the capture: RCCL sets its channels up lazily
+        ncclResult_t r = g_rccl.AllReduce(c->p.ctl->lt[0], c->p.ctl->lt_sum[0], 2 * c->cfg.k, ncclDouble, ncclSum, c->comm,
+                                          c->stream);
+        if (r != ncclSuccess) return fail(c, TSAMD_ECOMM, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+      }
       if (int rc = build_graph(c, kGraphSnps)) return rc;
+    }
     if ((uint32_t)(c->q & 1u) != c->graph_par0) enqueue_begin(c, 0xffffffffu, false);  // re-align parity
     for (uint32_t i = 0; i < n; i += kGraphSnps) HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
   } else {

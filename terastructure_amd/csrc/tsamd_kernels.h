@@ -99,8 +99,9 @@ __device__ __forceinline__ bool finish_pending(const DevParams &p, const Pending
   if (tid < J) {
     double lt = 0.0;
     for (uint32_t rr = 0; rr < R; ++rr) lt += s_fin[rr * J + tid];
-    lt *= in.eb_used;  // the b[k,t] factored out of the accumulation
-    const double nw = ((tid & 1u) ? p.eta1 : p.eta0) + lt;
+    // eta + b[k,t] * (row sum): the b factored out of the accumulation; an explicit fma so that
+    // every kernel that inlines this rounds the same way whatever the compiler would contract
+    const double nw = fma(lt, in.eb_used, (tid & 1u) ? p.eta1 : p.eta0);
     // exp(Elogbeta_kt) = exp(psi(lambda_kt) - psi(lambda_k0 + lambda_k1)) without a log: both
     // digammas in the split form z * exp(a) (tsamd_device.h), side by side in one instruction
     // stream; the pair sum comes from the neighbouring lane (t = 0/1 are adjacent threads)
