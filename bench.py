@@ -253,6 +253,30 @@ def main():
                 "first_pass_avg_us": round(pr["first_ms"] / max(1, pr["first_launches"]) * 1e3, 3),
             }
 
+    # second denominator: what a plain device-to-device copy reaches on this box,
+    # with the benchmark's data still resident (read + write bytes over the copy time)
+    if roofline is not None and world == 1:
+        try:
+            import torch
+
+            dev = torch.device("cuda", local_rank)
+            src = torch.empty(1 << 27, dtype=torch.float64, device=dev)  # 1 GiB
+            dst = torch.empty_like(src)
+            src.zero_()
+            for _ in range(2):
+                dst.copy_(src)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            ev1.record()
+            torch.cuda.synchronize(dev)
+            roofline["device_copy_GBps"] = round(10 * 2 * src.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
+            del src, dst
+        except Exception as exc:  # noqa: BLE001 -- an extra, never fatal
+            roofline["device_copy_GBps"] = None
+            print(f"[bench] device copy probe skipped: {exc}", file=sys.stderr, flush=True)
+
     # ---- CPU baseline: the oracle ("port") on the host cores, bounded sample ---------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
