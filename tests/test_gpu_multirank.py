@@ -48,7 +48,7 @@ def _run_ranks(tmp_path, mode, world, n, l, k, seed, nsnp):
     return [np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,n,k", [(2, 3000, 6), (4, 5003, 8), (3, 1000, 3)])
+@pytest.mark.parametrize("world,n,k", [(2, 3000, 6), (4, 5003, 8), (3, 1000, 3), (2, 4000, 20), (2, 2500, 40), (8, 9001, 8)])
 def test_p2p_sharded_matches_oracle(tmp_path, world, n, k):
     l, seed, nsnp = 32, 91, 40
     res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp)
