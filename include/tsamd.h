@@ -151,6 +151,15 @@ int tsamd_comm_init(tsamd_ctx *ctx, const uint8_t id[TSAMD_COMM_ID_BYTES]);
 int tsamd_p2p_export(tsamd_ctx *ctx, uint8_t handle[TSAMD_P2P_HANDLE_BYTES]);
 int tsamd_p2p_connect(tsamd_ctx *ctx, const uint8_t *handles /* [world][TSAMD_P2P_HANDLE_BYTES] */);
 
+/* The same exchange between contexts that live in ONE process (one context per GPU, ranks
+ * 0 .. world-1 in any order in ctxs[]): no handles, peer access is enabled between the
+ * devices.  The host then drives all shards from one thread the way the reference's main
+ * thread drives its workers (src/snpsamplinge.cc:320-366): enqueue the same call on every
+ * context (tsamd_run_schedule is asynchronous), then tsamd_synchronize each.  Calls that
+ * synchronise internally (tsamd_snp_update) would wait for peers that have not been
+ * enqueued yet: use tsamd_run_schedule + tsamd_synchronize in this mode. */
+int tsamd_p2p_connect_local(tsamd_ctx *const *ctxs, uint32_t count);
+
 /* ---- measurement / synthetic workloads ---------------------------------------- */
 /* Pritchard-Stephens-Donnelly genotypes straight into HBM for columns
  * [first_loc, first_loc + n_locs): y ~ Binomial(2, sum_k theta[n][k] * beta[j][k]),

@@ -300,6 +300,25 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
   geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", 512), p.chunk_first, c->grid_first);
 }
 
+// Switch the kernel sequence to the exchange buffer (rows + epoch flags pushed by every
+// workgroup to every rank); p.peers[] must be filled in.
+void activate_xchg(tsamd_ctx *c) {
+  c->p.xchg = c->xchg;
+  c->p.xchg_world = c->cfg.world;
+  c->p.xchg_rank = c->cfg.rank;
+  c->p.rows_from_lt = 0u;
+  c->split = true;
+  c->p2p = true;
+  configure_launch(c, std::max<uint32_t>(16u, std::min<uint32_t>(kXchgBlocks, 512u / c->cfg.world)));
+}
+
+int alloc_xchg(tsamd_ctx *c) {
+  if (c->xchg) return TSAMD_OK;
+  HIP_TRY(c, hipExtMallocWithFlags((void **)&c->xchg, sizeof(Xchg), hipDeviceMallocFinegrained));
+  HIP_TRY(c, hipMemset(c->xchg, 0, sizeof(Xchg)));
+  return TSAMD_OK;
+}
+
 int ensure_stage(tsamd_ctx *c, size_t bytes) {
   if (c->stage_bytes >= bytes) return TSAMD_OK;
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -911,10 +930,7 @@ int tsamd_p2p_export(tsamd_ctx *c, uint8_t handle[TSAMD_P2P_HANDLE_BYTES]) {
   static_assert(sizeof(hipIpcMemHandle_t) == TSAMD_P2P_HANDLE_BYTES, "hipIpcMemHandle_t size");
   if (c->cfg.world > (uint32_t)kMaxRanks) return fail(c, TSAMD_EUNSUPPORTED, "peer-to-peer exchange supports up to %d ranks", kMaxRanks);
   HIP_TRY(c, hipSetDevice(c->dev));
-  if (!c->xchg) {
-    HIP_TRY(c, hipExtMallocWithFlags((void **)&c->xchg, sizeof(Xchg), hipDeviceMallocFinegrained));
-    HIP_TRY(c, hipMemset(c->xchg, 0, sizeof(Xchg)));
-  }
+  if (int rc = alloc_xchg(c)) return rc;
   hipIpcMemHandle_t h;
   HIP_TRY(c, hipIpcGetMemHandle(&h, c->xchg));
   memcpy(handle, &h, sizeof h);
@@ -945,16 +961,53 @@ int tsamd_p2p_connect(tsamd_ctx *c, const uint8_t *handles) {
     c->peer_maps.push_back(ptr);
     c->p.peers[q] = (Xchg *)ptr;
   }
-  c->p.xchg = c->xchg;
-  c->p.xchg_world = c->cfg.world;
-  c->p.xchg_rank = c->cfg.rank;
-  c->p.rows_from_lt = 0u;
-  c->split = true;
-  c->p2p = true;
-  configure_launch(c, std::max<uint32_t>(16u, std::min<uint32_t>(kXchgBlocks, 512u / c->cfg.world)));
+  activate_xchg(c);
   if (c->wide && c->p.chunk_first > (uint32_t)kWideBlock * kWideItems)
     return fail(c, TSAMD_EUNSUPPORTED, "wide-K fallback: shard too large for the peer-to-peer launch geometry");
   destroy_graph(c);
+  return TSAMD_OK;
+}
+
+int tsamd_p2p_connect_local(tsamd_ctx *const *ctxs, uint32_t count) {
+  if (!ctxs || count == 0) return fail(nullptr, TSAMD_EINVAL, "no contexts");
+  tsamd_ctx *c0 = ctxs[0];
+  CHECK_CTX(c0);
+  if (count > (uint32_t)kMaxRanks) return fail(c0, TSAMD_EUNSUPPORTED, "peer-to-peer exchange supports up to %d ranks", kMaxRanks);
+  std::vector<tsamd_ctx *> by_rank(count, nullptr);
+  for (uint32_t i = 0; i < count; ++i) {
+    tsamd_ctx *c = ctxs[i];
+    if (!c) return fail(c0, TSAMD_EINVAL, "null context %u", i);
+    if (c->cfg.world != count || c->cfg.rank >= count || by_rank[c->cfg.rank])
+      return fail(c0, TSAMD_EINVAL, "contexts must be the ranks 0..%u of a world of %u, once each", count - 1, count);
+    if (c->p2p || c->comm) return fail(c0, TSAMD_EINVAL, "context of rank %u already has an exchange", c->cfg.rank);
+    if (c->cfg.n != c0->cfg.n || c->cfg.k != c0->cfg.k || c->cfg.l != c0->cfg.l)
+      return fail(c0, TSAMD_EINVAL, "contexts differ in n / l / k");
+    by_rank[c->cfg.rank] = c;
+  }
+  for (tsamd_ctx *c : by_rank) {
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rc = alloc_xchg(c)) return rc;
+    for (tsamd_ctx *o : by_rank) {
+      if (o->dev == c->dev) continue;
+      int can = 0;
+      HIP_TRY(c, hipDeviceCanAccessPeer(&can, c->dev, o->dev));
+      if (!can) return fail(c, TSAMD_ECOMM, "device %d cannot access device %d", c->dev, o->dev);
+      hipError_t e = hipDeviceEnablePeerAccess(o->dev, 0);
+      if (e == hipErrorPeerAccessAlreadyEnabled)
+        (void)hipGetLastError();
+      else if (e != hipSuccess)
+        return fail(c, TSAMD_ECOMM, "hipDeviceEnablePeerAccess(%d -> %d): %s", c->dev, o->dev, hipGetErrorString(e));
+    }
+  }
+  for (tsamd_ctx *c : by_rank) {
+    HIP_TRY(c, hipSetDevice(c->dev));
+    for (uint32_t q = 0; q < count; ++q) c->p.peers[q] = by_rank[q]->xchg;
+    activate_xchg(c);
+    if (c->wide && c->p.chunk_first > (uint32_t)kWideBlock * kWideItems)
+      return fail(c, TSAMD_EUNSUPPORTED, "wide-K fallback: shard too large for the peer-to-peer launch geometry");
+    destroy_graph(c);
+  }
   return TSAMD_OK;
 }
 

@@ -200,6 +200,15 @@ class Engine:
         buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
         self._check(self.h.tsamd_p2p_connect(self.ctx, buf))
 
+    @staticmethod
+    def p2p_connect_local(engines):
+        """Peer-to-peer exchange between engines of THIS process (ranks 0..world-1, one each).
+        Afterwards enqueue the same run_schedule on every engine, then synchronize each;
+        snp_update would wait for peers that have not been enqueued."""
+        arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
+        rc = engines[0].h.tsamd_p2p_connect_local(arr, len(engines))
+        engines[0]._check(rc)
+
     # -- measurement ------------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self.h.tsamd_profile_enable(self.ctx, int(on)))
