@@ -119,6 +119,7 @@ struct Options {
   bool use_test_set = false, compute_beta = false, logl = false, loadcmp = false;
   double seed = 0, stop_threshold = 1e-5;
   int device = 0;
+  std::vector<int> devices;  // extension: -devices a,b,...: shard the individuals over these GPUs
   uint32_t max_iter = 0;  // extension: stop after this many iterations (0 = reference behaviour)
 };
 
@@ -126,7 +127,8 @@ struct Run {
   Options o;
   std::string prefix;  // run directory
   FILE *plog = nullptr, *logf = nullptr, *vf = nullptr;
-  tsamd_ctx *ctx = nullptr;
+  tsamd_ctx *ctx = nullptr;            // shard 0 (the only one on a single GPU)
+  std::vector<tsamd_ctx *> ctxs;       // all shards, rank order
   time_t start_time = time(nullptr);
   uint32_t iter = 0;
   std::map<uint32_t, std::vector<uint32_t>> validation;  // loc -> ascending individuals
@@ -162,6 +164,40 @@ struct Run {
     if ((call) != 0) die(r, #call); \
   } while (0)
 
+// ---- the shards (one context per GPU; a single one unless -devices is given) ----------
+// Every operation goes to all shards from this thread, like the reference's main thread
+// driving its workers: enqueue on every context, then wait for each.
+void shard_span(const Run &r, size_t i, uint32_t &begin, uint32_t &count) {
+  tsamd_shard_range(r.o.n, (uint32_t)i, (uint32_t)r.ctxs.size(), &begin, &count);
+}
+
+void run_all(Run &r, const uint32_t *locs, uint32_t n, int hol_mode) {
+  if (tsamd_run_schedule_all(r.ctxs.data(), (uint32_t)r.ctxs.size(), locs, n, hol_mode) != 0) {
+    for (tsamd_ctx *c : r.ctxs)
+      if (*tsamd_last_error(c)) r.ctx = c;
+    die(r, "tsamd_run_schedule_all");
+  }
+  for (tsamd_ctx *c : r.ctxs)
+    if (tsamd_synchronize(c) != 0) {
+      r.ctx = c;
+      die(r, "tsamd_synchronize");
+    }
+}
+
+void set_gamma_all(Run &r, const std::vector<double> &g) {
+  for (size_t i = 0; i < r.ctxs.size(); ++i) {
+    uint32_t b, c;
+    shard_span(r, i, b, c);
+    TS(r, tsamd_set_gamma(r.ctxs[i], g.data() + (size_t)b * r.o.k));
+  }
+}
+
+void destroy_all(Run &r) {
+  for (tsamd_ctx *c : r.ctxs) tsamd_destroy(c);
+  r.ctxs.clear();
+  r.ctx = nullptr;
+}
+
 void usage() {
   fprintf(stdout,
           "Population inference software for SNP data (MI355X build).\n"
@@ -177,7 +213,8 @@ void usage() {
           "\t-rfreq <val>\t checks for convergence and logs output every <val> iterations\n"
           "\t-seed <val>\t random seed\n"
           "\t-compute-beta\t compute allele frequencies given ./gamma.txt\n"
-          "\t-device <id>\t HIP device ordinal (default 0)\n");
+          "\t-device <id>\t HIP device ordinal (default 0)\n"
+          "\t-devices <a,b,..>\t shard the individuals over these HIP devices (one shard each)\n");
   fflush(stdout);
 }
 
@@ -307,7 +344,7 @@ void read_bed(Run &r) {
       const uint8_t *col = buf.data() + j * r.bytes_per_snp;
       for (uint32_t i = 0; i < o.n; ++i) cnt[(col[i >> 2] >> (2 * (i & 3))) & 3]++;
     }
-    TS(r, tsamd_upload_bed(r.ctx, buf.data(), r.bytes_per_snp, loc, (uint32_t)got));
+    for (tsamd_ctx *c : r.ctxs) TS(r, tsamd_upload_bed(c, buf.data(), r.bytes_per_snp, loc, (uint32_t)got));
     loc += (uint32_t)got;
     if (loc % 20000 < got) {
       printf("\r%d locations read", loc);
@@ -365,7 +402,7 @@ void set_validation_sample(Run &r, Mt19937 &rng) {
     if (v.empty())
       r.validation.erase(loc);
     else
-      TS(r, tsamd_set_heldout(r.ctx, loc, v.data(), (uint32_t)v.size()));
+      for (tsamd_ctx *c : r.ctxs) TS(r, tsamd_set_heldout(c, loc, v.data(), (uint32_t)v.size()));
   } while (lm.size() < nlocs);
   r.plog_u("validation snps per location", per_loc_h);
   r.plog_u("validation locations", nlocs);
@@ -390,8 +427,12 @@ std::string add_iter_suffix(const Run &r, const char *c) {
 void save_model(Run &r) {
   const size_t n = r.o.n, k = r.o.k;
   std::vector<double> g(n * k), t(n * k);
-  TS(r, tsamd_get_gamma(r.ctx, g.data()));
-  TS(r, tsamd_get_theta(r.ctx, t.data()));
+  for (size_t i = 0; i < r.ctxs.size(); ++i) {
+    uint32_t b, c;
+    shard_span(r, i, b, c);
+    TS(r, tsamd_get_gamma(r.ctxs[i], g.data() + (size_t)b * k));
+    TS(r, tsamd_get_theta(r.ctxs[i], t.data() + (size_t)b * k));
+  }
   FILE *f = fopen(add_iter_suffix(r, "/gamma").c_str(), "w");
   FILE *h = fopen(add_iter_suffix(r, "/theta").c_str(), "w");
   if (!f || !h) {
@@ -420,14 +461,16 @@ bool compute_likelihood(Run &r, bool first) {
     const uint32_t loc = kv.first;
     printf("\rdone:%.2f%%", ((double)sz / r.validation.size()) * 100);
     if (!first) {  // snp_likelihood: optimize_lambda(loc) in hol mode, then _iter++
-      TS(r, tsamd_snp_update(r.ctx, loc, 1, nullptr));
+      run_all(r, &loc, 1, 1);
       r.iter++;
     }
-    double u = 0;
-    uint32_t c = 0;
-    TS(r, tsamd_heldout_loglik(r.ctx, loc, &u, &c));
-    s += u;
-    k += c;
+    for (tsamd_ctx *cx : r.ctxs) {  // ascending individuals: shard after shard
+      double u = 0;
+      uint32_t c = 0;
+      TS(r, tsamd_heldout_loglik(cx, loc, &u, &c));
+      s += u;
+      k += c;
+    }
     sz++;
   }
   fprintf(r.vf, "%d\t%d\t%.9f\t%d\t%f\n", r.iter, r.duration(), (s / k), k, exp(s / k));
@@ -510,7 +553,7 @@ void load_gamma(Run &r) {
     fprintf(stderr, "gamma.txt has %zu rows, expected %zu\n", row, n);
     exit(-1);
   }
-  TS(r, tsamd_set_gamma(r.ctx, g.data()));
+  set_gamma_all(r, g);
   FILE *f = fopen(r.file_str("/gammasave.txt").c_str(), "w");
   if (f) {
     for (size_t i = 0; i < n; ++i) {
@@ -528,8 +571,7 @@ void load_gamma(Run &r) {
 }
 
 void run_batch(Run &r, const std::vector<uint32_t> &locs) {
-  TS(r, tsamd_run_schedule(r.ctx, locs.data(), (uint32_t)locs.size(), 0));
-  TS(r, tsamd_synchronize(r.ctx));
+  run_all(r, locs.data(), (uint32_t)locs.size(), 0);
 }
 
 }  // namespace
@@ -612,6 +654,17 @@ int main(int argc, char **argv) {
       o.stop_threshold = atof(need(a));
     } else if (!strcmp(a, "-device")) {
       o.device = atoi(need(a));
+    } else if (!strcmp(a, "-devices")) {
+      o.devices.clear();
+      for (const char *q = need(a); *q;) {
+        char *e = nullptr;
+        o.devices.push_back((int)strtol(q, &e, 10));
+        if (e == q) {
+          fprintf(stdout, "error: -devices expects a comma separated list of device ordinals\n");
+          exit(-1);
+        }
+        q = (*e == ',') ? e + 1 : e;
+      }
     } else if (!strcmp(a, "-max-iter")) {
       o.max_iter = atoi(need(a));
     } else {
@@ -632,10 +685,22 @@ int main(int argc, char **argv) {
   // the GPU context comes first so that a missing device fails before any output exists
   tsamd_config cfg;
   tsamd_default_config(&cfg, o.n, o.l, o.k);
-  cfg.device = o.device;
   if (o.compute_beta) cfg.max_inner = 100;  // tightly optimize given the thetas (:75)
-  if (tsamd_create(&cfg, &r.ctx) != 0) {
-    fprintf(stderr, "error: tsamd_create: %s\n", tsamd_last_error(nullptr));
+  if (o.devices.empty()) o.devices.push_back(o.device);
+  cfg.world = (uint32_t)o.devices.size();
+  for (size_t i = 0; i < o.devices.size(); ++i) {
+    cfg.device = o.devices[i];
+    cfg.rank = (uint32_t)i;
+    tsamd_ctx *c = nullptr;
+    if (tsamd_create(&cfg, &c) != 0) {
+      fprintf(stderr, "error: tsamd_create: %s\n", tsamd_last_error(nullptr));
+      return -1;
+    }
+    r.ctxs.push_back(c);
+  }
+  r.ctx = r.ctxs[0];
+  if (r.ctxs.size() > 1 && tsamd_p2p_connect_local(r.ctxs.data(), (uint32_t)r.ctxs.size()) != 0) {
+    fprintf(stderr, "error: tsamd_p2p_connect_local: %s\n", tsamd_last_error(r.ctx));
     return -1;
   }
 
@@ -688,7 +753,7 @@ int main(int argc, char **argv) {
       fflush(stdout);
     }
     save_beta(r, o.locations_file == "" ? nullptr : &locs);
-    tsamd_destroy(r.ctx);
+    destroy_all(r);
     return 0;
   }
 
@@ -699,7 +764,7 @@ int main(int argc, char **argv) {
       const double v = (o.k < 100) ? 1.0 : (double)100.0 / o.k;
       g[i] = rng.gamma(100 * v, 0.01);
     }
-    TS(r, tsamd_set_gamma(r.ctx, g.data()));
+    set_gamma_all(r, g);
   }
   printf("+ computing initial heldout likelihood\n");
   compute_likelihood(r, true);
@@ -737,6 +802,6 @@ int main(int argc, char **argv) {
     }
   }
   printf("\n");
-  tsamd_destroy(r.ctx);
+  destroy_all(r);
   return 0;
 }

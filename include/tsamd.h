@@ -157,8 +157,14 @@ int tsamd_p2p_connect(tsamd_ctx *ctx, const uint8_t *handles /* [world][TSAMD_P2
  * thread drives its workers (src/snpsamplinge.cc:320-366): enqueue the same call on every
  * context (tsamd_run_schedule is asynchronous), then tsamd_synchronize each.  Calls that
  * synchronise internally (tsamd_snp_update) would wait for peers that have not been
- * enqueued yet: use tsamd_run_schedule + tsamd_synchronize in this mode. */
+ * enqueued yet: use tsamd_run_schedule_all + tsamd_synchronize in this mode. */
 int tsamd_p2p_connect_local(tsamd_ctx *const *ctxs, uint32_t count);
+/* tsamd_run_schedule on every context of such a group, interleaved in bounded batches: the
+ * kernels of one shard wait for the other shards' kernels, so a thread must never queue an
+ * unbounded amount of work on one context before the others have theirs (the device queue
+ * would fill up and the thread block with the peers' work still unsubmitted).  Asynchronous
+ * like tsamd_run_schedule; follow with tsamd_synchronize on each context. */
+int tsamd_run_schedule_all(tsamd_ctx *const *ctxs, uint32_t count, const uint32_t *locs, uint32_t n, int hol_mode);
 
 /* ---- measurement / synthetic workloads ---------------------------------------- */
 /* Pritchard-Stephens-Donnelly genotypes straight into HBM for columns

@@ -63,6 +63,7 @@ SYMBOLS = {
     "tsamd_p2p_export": (_int, [_vp, _pu8]),
     "tsamd_p2p_connect": (_int, [_vp, _pu8]),
     "tsamd_p2p_connect_local": (_int, [C.POINTER(_vp), _u32]),
+    "tsamd_run_schedule_all": (_int, [C.POINTER(_vp), _u32, _pu32, _u32, _int]),
     "tsamd_synth_genotypes": (_int, [_vp, _pd, _pd, _u32, _u32, _u64, _dbl]),
     "tsamd_profile_enable": (_int, [_vp, _int]),
     "tsamd_profile_read": (_int, [_vp, _pu64, _pd, _pu64, _pd]),

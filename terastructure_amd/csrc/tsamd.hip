@@ -1011,6 +1011,17 @@ int tsamd_p2p_connect_local(tsamd_ctx *const *ctxs, uint32_t count) {
   return TSAMD_OK;
 }
 
+int tsamd_run_schedule_all(tsamd_ctx *const *ctxs, uint32_t count, const uint32_t *locs, uint32_t n, int hol_mode) {
+  if (!ctxs || count == 0 || !ctxs[0]) return fail(nullptr, TSAMD_EINVAL, "no contexts");
+  // about 2K kernels per context and batch, a whole number of graph replays
+  const uint32_t per_snp = std::max<uint32_t>(1u, ctxs[0]->cfg.max_inner);
+  const uint32_t sub = std::max<uint32_t>(kGraphSnps, 2048u / per_snp / kGraphSnps * kGraphSnps);
+  for (uint32_t off = 0; off < n; off += sub)
+    for (uint32_t i = 0; i < count; ++i)
+      if (int rc = tsamd_run_schedule(ctxs[i], locs ? locs + off : nullptr, std::min(sub, n - off), hol_mode)) return rc;
+  return TSAMD_OK;
+}
+
 int tsamd_synth_genotypes(tsamd_ctx *c, const double *theta, const double *beta, uint32_t first_loc,
                           uint32_t n_locs, uint64_t seed, double missing_rate) {
   CHECK_CTX(c);

@@ -179,7 +179,10 @@ __device__ __forceinline__ void wait_peer_rows(const DevParams &p, uint32_t slot
   // a thread watches up to four flags at once (the flags are uncached: one poll is a trip to
   // memory, so the polls of one thread must not queue behind each other)
   const unsigned long long *seq = p.xchg->seq[slot];
-  for (uint32_t t0 = threadIdx.x; t0 < nflags; t0 += 4u * blockDim.x) {
+  // a peer already timed out: do not spend another bounded wait in every later launch (the
+  // results are void, tsamd_synchronize reports TSAMD_ECOMM)
+  const bool dead = __hip_atomic_load(&p.xchg->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
+  for (uint32_t t0 = threadIdx.x; t0 < nflags && !dead; t0 += 4u * blockDim.x) {
     const unsigned long long start = wall_clock64();  // 100 MHz
     while (true) {
       unsigned long long f[4];

@@ -209,6 +209,13 @@ class Engine:
         rc = engines[0].h.tsamd_p2p_connect_local(arr, len(engines))
         engines[0]._check(rc)
 
+    @staticmethod
+    def run_schedule_all(engines, locs, hol_mode=0):
+        """run_schedule on every engine of a p2p_connect_local group (bounded interleaving)."""
+        a = np.ascontiguousarray(locs, dtype=np.uint32)
+        arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
+        engines[0]._check(engines[0].h.tsamd_run_schedule_all(arr, len(engines), _up(a), a.size, int(hol_mode)))
+
     # -- measurement ------------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self.h.tsamd_profile_enable(self.ctx, int(on)))

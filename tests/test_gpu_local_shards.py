@@ -36,8 +36,7 @@ def test_local_shards_match_oracle(ts, world, n, k):
         ts.Engine.p2p_connect_local(engs)
         locs = np.random.default_rng(seed + 3).integers(0, l, size=50).astype(np.uint32)
         for part, hol in ((locs[:7], 0), (locs[7:8], 1), (locs[8:], 0)):   # eager, held-out mode, graph replay
-            for e in engs:
-                e.run_schedule(part, hol_mode=hol)
+            ts.Engine.run_schedule_all(engs, part, hol_mode=hol)
             for e in engs:
                 e.synchronize()
         its = [orc.snp_update(int(loc), 1 if i == 7 else 0) for i, loc in enumerate(locs)]
@@ -71,3 +70,32 @@ def test_local_connect_errors(ts):
     finally:
         a.close()
         b.close()
+
+
+def test_local_shards_deep_queue(ts):
+    """Far more kernels than a device queue holds (pass cap 100 as in -compute-beta, 1500
+    locations): run_schedule_all interleaves the shards in bounded batches, so the one driving
+    thread never blocks with a peer's work unsubmitted."""
+    world, n, l, k = 2, 2000, 1500, 4
+    y, _, _ = psd_genotypes(n, l, k, 77, 0.01)
+    payload = pack_bed(y)
+    gamma = init_gamma(n, k, 78)
+    engs = [ts.Engine(n, l, k, device=0, rank=r, world=world, max_inner=100) for r in range(world)]
+    ref = ts.Engine(n, l, k, max_inner=100)
+    try:
+        for e in engs + [ref]:
+            e.upload_bed(payload)
+            e.set_gamma(gamma[e.shard_begin:e.shard_begin + e.shard_count])
+        ts.Engine.p2p_connect_local(engs)
+        locs = np.arange(l, dtype=np.uint32)
+        ts.Engine.run_schedule_all(engs, locs)
+        for e in engs:
+            e.synchronize()
+        ref.run_schedule(locs)
+        ref.synchronize()
+        assert engs[0].total_passes() == ref.total_passes()
+        assert rel_err(engs[0].get_lambda(), ref.get_lambda()) < 1e-10
+        assert rel_err(np.concatenate([e.get_gamma() for e in engs]), ref.get_gamma()) < 1e-10
+    finally:
+        for e in engs + [ref]:
+            e.close()

@@ -114,3 +114,44 @@ def test_run_sh_end_to_end(host_bin, tmp_path):
     perm = min(itertools.permutations(range(3)), key=lambda p: np.mean((theta[:, list(p)] - truth_t) ** 2))
     truth_b = np.loadtxt(os.path.join(REF_DATA, "oracle_beta.txt"))
     assert np.sqrt(np.mean(((1 - beta[:, 1:][:, list(perm)]) - truth_b) ** 2)) <= 0.05
+
+
+@pytest.mark.gpu
+def test_run_sh_sharded_over_devices(host_bin, tmp_path):
+    """The same command with the individuals sharded (-devices; all shards on device 0 here):
+    same validation trajectory and stop iteration, theta within the stated tolerance of the
+    single-shard run's oracle."""
+    data = tmp_path / "data"
+    data.mkdir()
+    for f in ("test.bed", "test.bim", "test.fam"):
+        shutil.copy(os.path.join(REF_DATA, f), data / f)
+    cmd = [host_bin, "-file", "test.bed", "-n", "200", "-l", "10000", "-k", "3", "-stochastic",
+           "-nthreads", "1", "-rfreq", "1000", "-seed", "1234", "-label", "test", "-devices", "0,0,0"]
+    r = subprocess.run(cmd, cwd=data, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    run = data / "n200-k3-l10000-test-seed1234"
+    orc = op.Oracle(200, 10000, 3)
+    orc.read_bed_file(os.path.join(REF_DATA, "test.bed"))
+    res = orc.run(seed=1234, reportfreq=1000)
+    val = [line.split("\t") for line in open(run / "validation.txt").read().splitlines()]
+    assert len(val) == len(res["lines"]) == 17 and val[-1][0] == "16050"
+    for got, (it, ll, cnt) in zip(val, res["lines"]):
+        assert int(got[0]) == it and int(got[3]) == cnt
+        assert abs(float(got[2]) - ll) < 1e-8
+    theta = _read_matrix(run / "theta.txt")
+    assert theta.shape == (200, 3)
+    assert np.max(np.abs(theta - orc.theta())) <= 1e-6
+    # -compute-beta, sharded as well
+    cmd2 = [host_bin, "-file", "../test.bed", "-n", "200", "-l", "10000", "-k", "3", "-stochastic",
+            "-nthreads", "1", "-compute-beta", "-devices", "0,0"]
+    r = subprocess.run(cmd2, cwd=run, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    beta = _read_matrix(run / "n200-k3-l10000-xx" / "beta.txt")
+    gamma = _read_matrix(run / "gamma.txt")
+    o2 = op.Oracle(200, 10000, 3)
+    o2.read_bed_file(os.path.join(REF_DATA, "test.bed"))
+    rng = op.gsl_mt19937(0)
+    op.lib().orc_set_validation_sample(o2.s, C.byref(rng))
+    o2.set_gamma(gamma)
+    o2.compute_all_lambda()
+    assert np.max(np.abs(beta[:, 1:] - o2.ebeta())) <= 1e-6
