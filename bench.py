@@ -201,6 +201,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    barrier()  # (peer-to-peer: a rank's kernels wait at most 3 s for a peer that has not started yet)
     if args.warmup:
         eng.run_schedule(locs[:args.warmup])
     barrier()
