@@ -157,7 +157,9 @@ int tsamd_p2p_connect(tsamd_ctx *ctx, const uint8_t *handles /* [world][TSAMD_P2
  * thread drives its workers (src/snpsamplinge.cc:320-366): enqueue the same call on every
  * context (tsamd_run_schedule is asynchronous), then tsamd_synchronize each.  Calls that
  * synchronise internally (tsamd_snp_update) would wait for peers that have not been
- * enqueued yet: use tsamd_run_schedule_all + tsamd_synchronize in this mode. */
+ * enqueued yet: use tsamd_run_schedule_all + tsamd_synchronize in this mode.
+ * (Two contexts on the SAME device -- a test set-up, pointless otherwise -- need a hardware
+ * queue each: HIP maps streams onto GPU_MAX_HW_QUEUES queues, 4 by default, round-robin.) */
 int tsamd_p2p_connect_local(tsamd_ctx *const *ctxs, uint32_t count);
 /* tsamd_run_schedule on every context of such a group, interleaved in bounded batches: the
  * kernels of one shard wait for the other shards' kernels, so a thread must never queue an

@@ -127,7 +127,8 @@ def test_run_sh_sharded_over_devices(host_bin, tmp_path):
         shutil.copy(os.path.join(REF_DATA, f), data / f)
     cmd = [host_bin, "-file", "test.bed", "-n", "200", "-l", "10000", "-k", "3", "-stochastic",
            "-nthreads", "1", "-rfreq", "1000", "-seed", "1234", "-label", "test", "-devices", "0,0,0"]
-    r = subprocess.run(cmd, cwd=data, capture_output=True, text=True, timeout=240)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")  # shards sharing a device need a hardware queue each
+    r = subprocess.run(cmd, cwd=data, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
     run = data / "n200-k3-l10000-test-seed1234"
     orc = op.Oracle(200, 10000, 3)
@@ -144,7 +145,7 @@ def test_run_sh_sharded_over_devices(host_bin, tmp_path):
     # -compute-beta, sharded as well
     cmd2 = [host_bin, "-file", "../test.bed", "-n", "200", "-l", "10000", "-k", "3", "-stochastic",
             "-nthreads", "1", "-compute-beta", "-devices", "0,0"]
-    r = subprocess.run(cmd2, cwd=run, capture_output=True, text=True, timeout=240)
+    r = subprocess.run(cmd2, cwd=run, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     beta = _read_matrix(run / "n200-k3-l10000-xx" / "beta.txt")
     gamma = _read_matrix(run / "gamma.txt")
