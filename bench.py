@@ -196,8 +196,14 @@ def main():
 
     locs = np.random.default_rng(args.seed + 3).integers(0, l, size=args.warmup + args.steps).astype(np.uint32)
 
+    import torch
+
+    def device_sync():
+        eng.synchronize()                      # the engine's own stream (errors surface here)
+        torch.cuda.synchronize(local_rank)     # and the whole device, as the bench contract words it
+
     def barrier():
-        eng.synchronize()
+        device_sync()
         if dist is not None:
             dist.barrier()
 
@@ -208,7 +214,7 @@ def main():
     p0 = eng.total_passes()
     t0 = time.perf_counter()
     eng.run_schedule(locs[args.warmup:])
-    eng.synchronize()
+    device_sync()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
