@@ -212,6 +212,7 @@ def main():
         eng.run_schedule(locs[:args.warmup])
     barrier()
     p0 = eng.total_passes()
+    h0 = eng.pass_histogram()
     t0 = time.perf_counter()
     eng.run_schedule(locs[args.warmup:])
     device_sync()
@@ -219,6 +220,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     passes = eng.total_passes() - p0
+    hist = eng.pass_histogram() - h0
     if dist is not None:
         import torch
 
@@ -326,6 +328,7 @@ def main():
                        "parallelism": f"individual-shard x{world}", "exchange": exchange,
                        "exchange_selftest_updates_per_s": exchange_rates},
             "mean_inner_passes": round(mean_passes, 3),
+            "inner_passes_histogram": {str(i): int(c) for i, c in enumerate(hist) if c},
             "nk_pass_per_s": round(value * mean_passes * n * k, 1),
             "update_algorithmic_bytes": alg_update,
             "update_hbm_frac_of_peak": round(alg_update * value / (world * HBM_PEAK_GBS * 1e9), 4),

@@ -123,6 +123,11 @@ int tsamd_run_schedule(tsamd_ctx *ctx, const uint32_t *locs, uint32_t n, int hol
 int tsamd_synchronize(tsamd_ctx *ctx);
 /* total inner passes executed by tsamd_run_schedule / snp_update calls since creation */
 int tsamd_total_passes(tsamd_ctx *ctx, uint64_t *passes);
+/* completed SNP updates since creation by the number of inner passes they ran: hist[i] for
+ * i passes, i < TSAMD_PASS_HIST_BINS - 1; the last bin collects everything above.  (The bytes a
+ * SNP-minibatch update moves depend on its pass count.) */
+#define TSAMD_PASS_HIST_BINS 128
+int tsamd_pass_histogram(tsamd_ctx *ctx, uint64_t hist[TSAMD_PASS_HIST_BINS]);
 /* drop the pending gamma step (a new process starts with none: `first`, :652) */
 int tsamd_clear_pending(tsamd_ctx *ctx);
 

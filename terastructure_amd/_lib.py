@@ -11,6 +11,7 @@ COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
 FLAG_SPLIT_EPILOGUE = 1
 FLAG_NO_GRAPH = 2
+PASS_HIST_BINS = 128
 
 
 class Config(C.Structure):
@@ -56,6 +57,7 @@ SYMBOLS = {
     "tsamd_run_schedule": (_int, [_vp, _pu32, _u32, _int]),
     "tsamd_synchronize": (_int, [_vp]),
     "tsamd_total_passes": (_int, [_vp, _pu64]),
+    "tsamd_pass_histogram": (_int, [_vp, _pu64]),
     "tsamd_clear_pending": (_int, [_vp]),
     "tsamd_heldout_loglik": (_int, [_vp, _u32, _pd, _pu32]),
     "tsamd_comm_unique_id": (_int, [_pu8]),

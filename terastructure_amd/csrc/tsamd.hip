@@ -850,6 +850,16 @@ int tsamd_total_passes(tsamd_ctx *c, uint64_t *passes) {
   return TSAMD_OK;
 }
 
+int tsamd_pass_histogram(tsamd_ctx *c, uint64_t hist[TSAMD_PASS_HIST_BINS]) {
+  CHECK_CTX(c);
+  if (!hist) return fail(c, TSAMD_EINVAL, "null output");
+  HIP_TRY(c, hipSetDevice(c->dev));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "histogram element size");
+  HIP_TRY(c, hipMemcpy(hist, c->p.ctl->pass_hist, sizeof(uint64_t) * TSAMD_PASS_HIST_BINS, hipMemcpyDeviceToHost));
+  return TSAMD_OK;
+}
+
 int tsamd_clear_pending(tsamd_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->dev));

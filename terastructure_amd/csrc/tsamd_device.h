@@ -43,6 +43,7 @@ struct Ctl {
   uint32_t sched_len;   // entries in the schedule; kernels past the end only carry state forward
   uint32_t last_iters;  // inner passes of the most recently completed SNP (for tsamd_snp_update)
   unsigned long long total_passes;
+  unsigned long long pass_hist[TSAMD_PASS_HIST_BINS];  // completed SNPs by inner passes run (last bin: that many or more)
   State st[2];
   double lt[2][2 * TSAMD_MAX_K];      // sharded: this shard's summed partial rows (all-reduce input)
   double lt_sum[2][2 * TSAMD_MAX_K];  // all-reduced; read as the single "row" of the previous pass

@@ -140,6 +140,7 @@ __device__ __forceinline__ void publish_complete(const DevParams &p, Ctl *ctl, c
   if (tid == 0) {
     ctl->last_iters = S->iters;
     ctl->total_passes += (unsigned long long)S->iters;
+    ctl->pass_hist[min(S->iters, (uint32_t)TSAMD_PASS_HIST_BINS - 1u)] += 1ull;
     if (write_state) {
       W->idx = S->idx;
       W->valid = 1u;

@@ -167,6 +167,12 @@ class Engine:
         self._check(self.h.tsamd_total_passes(self.ctx, C.byref(v)))
         return v.value
 
+    def pass_histogram(self):
+        """completed SNP updates by inner passes run (index = passes; last bin = that many or more)"""
+        h = np.zeros(_lib.PASS_HIST_BINS, dtype=np.uint64)
+        self._check(self.h.tsamd_pass_histogram(self.ctx, h.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return h
+
     def clear_pending(self):
         self._check(self.h.tsamd_clear_pending(self.ctx))
 

@@ -155,6 +155,7 @@ def test_trajectory_matches_oracle(ts, n, l, k):
         assert its_d == its_o
         assert_state_close(eng, orc, 1e-9, f"n={n}")
         assert eng.total_passes() == sum(its_o)
+        assert np.array_equal(eng.pass_histogram(), np.bincount(its_o, minlength=128).astype(np.uint64))
 
 
 def test_run_schedule_equals_snp_updates_bitwise(ts):
