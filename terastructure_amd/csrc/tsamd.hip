@@ -194,7 +194,10 @@ void enqueue_begin(tsamd_ctx *c, uint32_t n, bool drop_pending) {
 }
 
 void enqueue_flush(tsamd_ctx *c) {
-  hipLaunchKernelGGL(ts_flush, dim3(1), dim3(512), 0, c->stream, c->p, next_parity(c));
+  if (c->wide)
+    hipLaunchKernelGGL((ts_flush<kWideBlock>), dim3(1), dim3(kWideBlock), 0, c->stream, c->p, next_parity(c));
+  else  // 256 = workgroup size of ts_pass<K, true, ...>
+    hipLaunchKernelGGL((ts_flush<256>), dim3(1), dim3(256), 0, c->stream, c->p, next_parity(c));
 }
 
 // profiling: one HIP-event pair around the first pass and one around the run of plain

@@ -662,8 +662,12 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
 #ifdef TSAMD_MAIN_TU  // K-independent kernels: compiled into tsamd.hip only
 // End of a schedule: complete the pending pass so that lambda/eb in the global arrays are
 // final (whole SNPs only are ever enqueued, so the pending pass is the SNP's last).
-__global__ __launch_bounds__(512) void ts_flush(DevParams p, uint32_t par) {
-  __shared__ double s_fin[512];
+// BLOCK is the workgroup size of the first-pass kernel, which would otherwise finish this pass
+// (at the start of the next SNP): same (row group, value) mapping, same summation order, so a
+// schedule cut anywhere gives the same bits as the uncut one.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ts_flush(DevParams p, uint32_t par) {
+  __shared__ double s_fin[BLOCK];
   __shared__ double s_lam[2 * TSAMD_MAX_K];
   __shared__ double s_eb[2 * TSAMD_MAX_K];
   __shared__ double s_diff[2 * TSAMD_MAX_K];
@@ -678,8 +682,8 @@ __global__ __launch_bounds__(512) void ts_flush(DevParams p, uint32_t par) {
     const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                           : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
                                            : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
-    const double vrow = p.xchg_world ? row_partial_sum_xchg<512>(rowsR, nrowsR, J) : row_partial_sum<512>(rowsR, nrowsR, J);
-    finish_pending<512>(p, pin, vrow, J, s_fin, s_lam, s_eb, s_diff);
+    const double vrow = p.xchg_world ? row_partial_sum_xchg<BLOCK>(rowsR, nrowsR, J) : row_partial_sum<BLOCK>(rowsR, nrowsR, J);
+    finish_pending<BLOCK>(p, pin, vrow, J, s_fin, s_lam, s_eb, s_diff);
     publish_complete(p, ctl, S, W, J, s_lam, s_eb, true);
   } else {
     carry_state(S, W, J);

@@ -158,10 +158,11 @@ def test_trajectory_matches_oracle(ts, n, l, k):
         assert np.array_equal(eng.pass_histogram(), np.bincount(its_o, minlength=128).astype(np.uint64))
 
 
-def test_run_schedule_equals_snp_updates_bitwise(ts):
+@pytest.mark.parametrize("n,l,k", [(4000, 64, 8), (90000, 40, 5), (600000, 40, 8)])
+def test_run_schedule_equals_snp_updates_bitwise(ts, n, l, k):
     """run_schedule (hipGraph replay) == n x snp_update (eager), bit for bit, and is
-    reproducible run to run (fixed reduction order)."""
-    n, l, k = 4000, 64, 8
+    reproducible run to run (fixed reduction order) -- also at sizes where a pass leaves more
+    partial rows than one load batch and the plain pass runs 512-thread workgroups."""
     rng = np.random.default_rng(9)
     locs = rng.integers(0, l, size=37).astype(np.uint32)
     outs = []
@@ -183,10 +184,10 @@ def test_run_schedule_equals_snp_updates_bitwise(ts):
         assert o[3] == outs[0][3]
 
 
-def test_split_epilogue_path_bitwise(ts):
+@pytest.mark.parametrize("n,l,k", [(3000, 32, 6), (90000, 32, 6)])
+def test_split_epilogue_path_bitwise(ts, n, l, k):
     """The sharded kernel sequence (pass -> row sum -> exchange) with one shard gives the
     same bits as the single-GPU sequence."""
-    n, l, k = 3000, 32, 6
     locs = np.random.default_rng(4).integers(0, l, size=20).astype(np.uint32)
     res = []
     for flags in (0, ts.FLAG_SPLIT_EPILOGUE):
