@@ -136,7 +136,9 @@ int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
   if (!(ctx)) return TSAMD_EINVAL
 
 // launchers of the K-specialised kernels, one per translation unit (tsamd_inst.hip)
-#define TSAMD_DECL(k) void launch_k##k(int, uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, uint32_t);
+#define TSAMD_DECL(k)                                                                              \
+  void launch_k##k(int, uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, uint32_t); \
+  int first_blocks_per_cu_k##k(int);
 #define TSAMD_ALL_K(X)                                                                             \
   X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)     \
   X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
@@ -147,6 +149,8 @@ TSAMD_ALL_K(TSAMD_DECL)
 namespace {
 #define TSAMD_ENTRY(k) tsamd::launch_k##k,
 const LaunchFn kLaunchers[TSAMD_SPECIALIZED_K + 1] = {nullptr, TSAMD_ALL_K(TSAMD_ENTRY)};
+#define TSAMD_OCC_ENTRY(k) tsamd::first_blocks_per_cu_k##k,
+int (*const kFirstBlocksPerCu[TSAMD_SPECIALIZED_K + 1])(int) = {nullptr, TSAMD_ALL_K(TSAMD_OCC_ENTRY)};
 
 __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -300,7 +304,16 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
   c->block = block;
   c->first_vec = env_u32("TSAMD_FIRST_VEC", 1) == 2 ? 2 : 1;
   geometry(p.npairs, block, env_u32("TSAMD_GRID", 256), p.chunk, c->grid);
-  geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", 512), p.chunk_first, c->grid_first);
+  // first pass: exactly as many workgroups as are resident at once (one round; the kernel is
+  // register-bound, so that is 2 per compute unit at K = 8 and 1 from K = 12 on)
+  uint32_t first_target = 512;
+  {
+    hipDeviceProp_t prop;
+    const int nb = kFirstBlocksPerCu[c->cfg.k]((int)c->first_vec);
+    if (nb > 0 && hipGetDeviceProperties(&prop, c->dev) == hipSuccess && prop.multiProcessorCount > 0)
+      first_target = (uint32_t)prop.multiProcessorCount * (uint32_t)std::min(nb, 4);
+  }
+  geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", first_target), p.chunk_first, c->grid_first);
 }
 
 // Switch the kernel sequence to the exchange buffer (rows + epoch flags pushed by every

@@ -36,4 +36,13 @@ void TSAMD_CAT(launch_k, TSAMD_K)(int which, uint32_t grid, uint32_t block, hipS
   }
 }
 
+// resident first-pass workgroups per compute unit (register-bound: 2 at K = 8, 1 from K = 12)
+int TSAMD_CAT(first_blocks_per_cu_k, TSAMD_K)(int vec) {
+  constexpr int K = TSAMD_K;
+  int nb = 0;
+  const hipError_t e = vec == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ts_pass<K, true, 256, 2>, 256, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ts_pass<K, true, 256, 1>, 256, 0);
+  return e == hipSuccess ? nb : 0;
+}
+
 }  // namespace tsamd
