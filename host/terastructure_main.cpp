@@ -136,6 +136,7 @@ struct Run {
   double prev_h = -2147483647, max_h = -2147483647;
   uint32_t nh = 0;
   std::string bed_path;
+  std::vector<uint8_t> text_payload;   // .012 input: the columns re-packed as PLINK codes, kept for read_column
   uint64_t bytes_per_snp = 0;
 
   std::string file_str(const std::string &f) const { return prefix + f; }
@@ -203,7 +204,8 @@ void usage() {
           "Population inference software for SNP data (MI355X build).\n"
           "terastructure [OPTIONS]\n"
           "\t-help\t\tusage\n"
-          "\t-file <name>\t PLINK .bed file (SNP-major); .bim/.fam are found next to it\n"
+          "\t-file <name>\t PLINK .bed file (SNP-major; .bim/.fam are found next to it), or a .012 text file\n"
+          "\t\t\t (one line per location, one character 0/1/2/- per individual)\n"
           "\t-bfile <prefix>\t same as -file <prefix>.bed\n"
           "\t-n <N>\t\t number of individuals\n"
           "\t-l <L>\t\t number of locations\n"
@@ -362,7 +364,80 @@ void read_bed(Run &r) {
   r.plog_u("2s snps", cnt[0]);
 }
 
+// SNP::read, text branch (src/snp.cc:16-92): one line per location, one character per
+// individual: '0' '1' '2' = copies of the counted allele, '-' = missing.  Each line is re-packed
+// into the PLINK 2-bit codes the engine stores (0 -> 00, 1 -> 10, 2 -> 11, missing -> 01); the
+// format is for small data, so the packed columns stay in host memory for the held-out
+// sampling.  (The reference reads into a 20 KB line buffer; any line length works here.)
+void read_012(Run &r) {
+  const Options &o = r.o;
+  printf("+ .012 detected");
+  fprintf(stdout, "+ reading (%d,%d) snps from %s\n", o.n, o.l, o.datfname.c_str());
+  fflush(stdout);
+  FILE *f = fopen(o.datfname.c_str(), "r");
+  if (!f) {
+    r.lerr("cannot open file %s:%s", o.datfname.c_str(), strerror(errno));
+    fprintf(stderr, "cannot open file %s:%s\n", o.datfname.c_str(), strerror(errno));
+    exit(-1);
+  }
+  r.bytes_per_snp = ((uint64_t)o.n + 3) / 4;
+  r.text_payload.assign((size_t)o.l * r.bytes_per_snp, 0);
+  uint64_t missing = 0, a[3] = {0, 0, 0};
+  static const uint8_t code_of_y[3] = {0u, 2u, 3u};
+  char *line = nullptr;
+  size_t cap = 0;
+  uint32_t loc = 0;
+  while (loc < o.l) {
+    ssize_t len = getline(&line, &cap, f);
+    if (len < 0) break;
+    while (len > 0 && (line[len - 1] == '\n' || line[len - 1] == '\r' || line[len - 1] == ' ')) --len;
+    if (len == 0) continue;
+    if ((size_t)len < o.n) {
+      printf("Error: unexpected lines in file\n");
+      exit(-1);
+    }
+    uint8_t *col = r.text_payload.data() + (size_t)loc * r.bytes_per_snp;
+    for (uint32_t i = 0; i < o.n; ++i) {
+      uint8_t code;
+      if (line[i] == '-') {
+        missing++;
+        code = 1u;
+      } else if (line[i] >= '0' && line[i] <= '2') {
+        a[line[i] - '0']++;
+        code = code_of_y[line[i] - '0'];
+      } else {
+        fprintf(stderr, "%s: unexpected character '%c' at location %u\n", o.datfname.c_str(), line[i], loc);
+        exit(-1);
+      }
+      col[i >> 2] |= (uint8_t)(code << (2 * (i & 3)));
+    }
+    loc++;
+    if (loc % 10000 == 0) {
+      printf("\r%d locations read", loc);
+      fflush(stdout);
+    }
+  }
+  free(line);
+  fclose(f);
+  if (loc != o.l) {
+    fprintf(stderr, "%s is truncated: %u of %u locations\n", o.datfname.c_str(), loc, o.l);
+    exit(-1);
+  }
+  const uint32_t batch = (uint32_t)std::max<size_t>(1, (size_t)(64u << 20) / r.bytes_per_snp);
+  for (uint32_t l0 = 0; l0 < o.l; l0 += batch)
+    for (tsamd_ctx *c : r.ctxs)
+      TS(r, tsamd_upload_bed(c, r.text_payload.data() + (size_t)l0 * r.bytes_per_snp, r.bytes_per_snp, l0,
+                             std::min(batch, o.l - l0)));
+  r.plog_u("missing snps", missing);
+  r.plog_u("0s snps", a[0]);
+  r.plog_u("1s snps", a[1]);
+  r.plog_u("2s snps", a[2]);
+}
+
 std::vector<uint8_t> read_column(Run &r, uint32_t loc) {
+  if (!r.text_payload.empty())
+    return std::vector<uint8_t>(r.text_payload.begin() + (size_t)loc * r.bytes_per_snp,
+                                r.text_payload.begin() + (size_t)(loc + 1) * r.bytes_per_snp);
   std::vector<uint8_t> col(r.bytes_per_snp);
   FILE *f = fopen(r.bed_path.c_str(), "rb");
   if (!f || fseeko(f, 3 + (off_t)loc * (off_t)r.bytes_per_snp, SEEK_SET) != 0 ||
@@ -705,7 +780,19 @@ int main(int argc, char **argv) {
   }
 
   setup_run_dir(r);
-  read_bed(r);
+  {  // SNP::read (src/snp.cc:9-21): the extension decides
+    const std::string ext = o.datfname.size() >= 4 ? o.datfname.substr(o.datfname.size() - 4) : "";
+    if (ext == ".bed") {
+      printf("+ bed format detected\n");
+      read_bed(r);
+    } else if (ext == ".012") {
+      read_012(r);
+    } else {
+      r.lerr("unrecognized file extension");
+      fprintf(stderr, "unrecognized file extension\n");
+      exit(-1);
+    }
+  }
   printf("+ initialization begin\n");
   fflush(stdout);
   r.plog_u("individuals n", o.n);

@@ -156,3 +156,41 @@ def test_run_sh_sharded_over_devices(host_bin, tmp_path):
     o2.set_gamma(gamma)
     o2.compute_all_lambda()
     assert np.max(np.abs(beta[:, 1:] - o2.ebeta())) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_text_012_input_equals_bed(host_bin, tmp_path):
+    """SNP::read's other branch (src/snp.cc:16-92): the same genotypes as a .012 text file give
+    byte-identical outputs to the .bed run (same packed columns on the device)."""
+    from helpers import unpack_bed
+
+    data = tmp_path / "data"
+    data.mkdir()
+    for f in ("test.bed", "test.bim", "test.fam"):
+        shutil.copy(os.path.join(REF_DATA, f), data / f)
+    raw = np.fromfile(data / "test.bed", dtype=np.uint8)[3:].reshape(10000, 50)
+    y = unpack_bed(raw, 200)
+    chars = np.array(list("012-"))
+    with open(data / "test.012", "w") as f:
+        for row in y:
+            f.write("".join(chars[row]) + "\n")
+    outs = {}
+    for name in ("test.bed", "test.012"):
+        cmd = [host_bin, "-file", name, "-n", "200", "-l", "10000", "-k", "3", "-stochastic", "-nthreads", "1",
+               "-rfreq", "1000", "-seed", "77", "-label", name[-3:], "-max-iter", "3000"]
+        r = subprocess.run(cmd, cwd=data, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+        run = data / f"n200-k3-l10000-{name[-3:]}-seed77"
+        outs[name] = {f: open(run / f).read() for f in ("theta.txt", "gamma.txt", "validation.txt", "param.txt")}
+    b, t = outs["test.bed"], outs["test.012"]
+    assert b["theta.txt"] == t["theta.txt"] and b["gamma.txt"] == t["gamma.txt"]
+    assert [ln.split("\t")[0::2] for ln in b["validation.txt"].splitlines()] == \
+           [ln.split("\t")[0::2] for ln in t["validation.txt"].splitlines()]      # iteration, log likelihood, likelihood
+    cnt = lambda txt, key: int([ln for ln in txt.splitlines() if ln.startswith(key)][0].split(": ")[1])  # noqa: E731
+    assert cnt(t["param.txt"], "missing snps") == cnt(b["param.txt"], "missing snps") == int((y == 3).sum())
+    assert cnt(t["param.txt"], "0s snps") == int((y == 0).sum()) == cnt(b["param.txt"], "2s snps")   # (.bed labels are swapped in the reference)
+    assert cnt(t["param.txt"], "2s snps") == int((y == 2).sum())
+    # unknown extensions are refused like the reference does
+    r = subprocess.run([host_bin, "-file", "test.txt", "-n", "200", "-l", "10000", "-k", "3"], cwd=data,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "unrecognized file extension" in r.stderr
