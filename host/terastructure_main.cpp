@@ -136,6 +136,7 @@ struct Run {
   double prev_h = -2147483647, max_h = -2147483647;
   uint32_t nh = 0;
   std::string bed_path;
+  std::vector<std::string> labels;      // -idfile: individual labels, echoed into gammasave.txt
   std::vector<uint8_t> text_payload;   // .012 input: the columns re-packed as PLINK codes, kept for read_column
   uint64_t bytes_per_snp = 0;
 
@@ -596,6 +597,19 @@ void save_beta(Run &r, const std::vector<uint32_t> *locs) {
   fclose(f);
 }
 
+// SNP::read_idfile (src/snp.cc:255-276): one whitespace-separated label per individual, in order
+void read_idfile(Run &r) {
+  FILE *f = fopen(r.o.idfile.c_str(), "r");
+  if (!f) {
+    r.lerr("cannot open file %s:%s", r.o.idfile.c_str(), strerror(errno));
+    fprintf(stderr, "error reading %s; quitting\n", r.o.idfile.c_str());
+    exit(-1);
+  }
+  char tok[128];
+  while (fscanf(f, "%127s", tok) == 1) r.labels.push_back(tok);
+  fclose(f);
+}
+
 // load_gamma (src/snpsamplinge.cc:800-862): ./gamma.txt of the CURRENT directory
 void load_gamma(Run &r) {
   const size_t n = r.o.n, k = r.o.k;
@@ -632,7 +646,7 @@ void load_gamma(Run &r) {
   FILE *f = fopen(r.file_str("/gammasave.txt").c_str(), "w");
   if (f) {
     for (size_t i = 0; i < n; ++i) {
-      fprintf(f, "%zu\t%s\t", i, "unknown");
+      fprintf(f, "%zu\t%s\t", i, (i < r.labels.size() && !r.labels[i].empty()) ? r.labels[i].c_str() : "unknown");
       double mx = .0;
       size_t mk = 0;
       for (size_t j = 0; j < k; ++j) {
@@ -706,6 +720,7 @@ int main(int argc, char **argv) {
       o.logl = true;
     } else if (!strcmp(a, "-idfile")) {
       o.idfile = need(a);  // labels are only echoed into gammasave.txt by the reference
+      fprintf(stdout, "+ idfile = %s\n", o.idfile.c_str());
     } else if (!strcmp(a, "-loadcmp")) {
       o.loadcmp = true;
     } else if (!strcmp(a, "-seed")) {
@@ -793,6 +808,7 @@ int main(int argc, char **argv) {
       exit(-1);
     }
   }
+  if (o.idfile != "") read_idfile(r);  // (src/main.cc:208)
   printf("+ initialization begin\n");
   fflush(stdout);
   r.plog_u("individuals n", o.n);

@@ -93,14 +93,18 @@ def test_run_sh_end_to_end(host_bin, tmp_path):
     assert raw.count("\n") == 200 and raw.split("\n")[0].endswith("\t")   # "%.8f\t" * K + "\n"
 
     # data/run.sh lines 2-3: -compute-beta from inside the run directory
+    with open(run / "ids.txt", "w") as f:       # -idfile: labels echoed into gammasave.txt (src/snp.cc:255-276)
+        f.write("\n".join(f"ind{i}" for i in range(150)) + "\n")
     cmd2 = [host_bin, "-file", "../test.bed", "-n", "200", "-l", "10000", "-k", "3", "-stochastic",
-            "-nthreads", "1", "-compute-beta"]
+            "-nthreads", "1", "-compute-beta", "-idfile", "ids.txt"]
     r = subprocess.run(cmd2, cwd=run, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     bdir = run / "n200-k3-l10000-xx"
     beta = _read_matrix(bdir / "beta.txt")
     assert beta.shape == (10000, 4) and np.array_equal(beta[:, 0], np.arange(10000))
-    assert (bdir / "gammasave.txt").exists()
+    gs = open(bdir / "gammasave.txt").read().splitlines()
+    assert len(gs) == 200 and gs[0].split("\t")[:2] == ["0", "ind0"] and gs[149].split("\t")[1] == "ind149"
+    assert gs[150].split("\t")[1] == "unknown"
     # same sweep in the oracle: gamma re-read from the %.8f text, fresh default-seed validation sample
     o2 = op.Oracle(200, 10000, 3)
     o2.read_bed_file(os.path.join(REF_DATA, "test.bed"))
