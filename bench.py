@@ -14,6 +14,10 @@ lambda statistics are exchanged inside libtsamd -- peer-to-peer stores over xGMI
 when the start-up self-test passes, RCCL all-reduce otherwise (strong scaling:
 N individuals fixed).  torch.distributed (gloo) only carries the bootstrap
 handles and the timing barriers.
+
+Everything the timed region needs is built before it starts whatever --warmup is
+(tsamd_prepare: the replayed hipGraphs), and a schedule of any length replays without
+padding, so `--steps 20 --warmup 5` measures the same per-update time as a long run.
 """
 import argparse
 import json
@@ -27,7 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+from helpers import rel_err, usable_cores  # noqa: E402  (tests/helpers.py: numpy only)
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SELFTEST_TOL = 1e-9    # exchange self-test: lambda / gamma vs the CPU oracle after 6 updates (rel)
 
 
 def parse():
@@ -46,57 +53,89 @@ def parse():
     return ap.parse_args()
 
 
-def usable_cores():
-    """Host cores this process may really use: the smaller of the affinity mask and the
-    cgroup CPU quota (a container can see 256 CPUs and be entitled to 16)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        try:  # cgroup v1
-            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if quota > 0:
-                n = min(n, max(1, quota // period))
-        except (OSError, ValueError):
-            pass
-    return n
+def fail_together(ok, dist, what):
+    """Every rank leaves with a non-zero status if any rank failed (no rank is left waiting in a
+    barrier for a peer that raised)."""
+    if dist is not None:
+        from terastructure_amd import dist as tdist
+
+        ok = tdist.all_ok(ok, dist)
+    if not ok:
+        print(f"[bench] FAILED: {what}", file=sys.stderr, flush=True)
+        if dist is not None:
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+        sys.exit(3)
 
 
-def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_shard):
+def gather_bytes(local, dist, rank):
+    """rank 0 gets every rank's byte array (list in rank order); others get None"""
+    out = [None] * dist.get_world_size() if rank == 0 else None
+    dist.gather_object(local, out, dst=0)
+    return out
+
+
+def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_full, shard, cores):
     """Per-pass exchange of the 2K lambda statistics: direct peer-to-peer stores over xGMI or
     the RCCL all-reduce.  Both are run on this node on the benchmark's own shards (a few SNP
-    columns, a short schedule): peer-to-peer is used when it reproduces the RCCL result and is
-    not slower.  TSAMD_EXCHANGE=rccl|p2p forces one."""
+    columns, a short schedule) and checked (a) against the CPU oracle run by rank 0 on the same
+    columns -- lambda, gamma and c_n after 6 updates -- and (b) against each other after 260.
+    Peer-to-peer is used when it is valid and not slower; an exchange that fails its check is
+    never timed.  TSAMD_EXCHANGE=rccl|p2p restricts the candidates (the check still runs)."""
     import torch
 
+    import oracle_py as op
     from terastructure_amd import dist as tdist
 
     forced = os.environ.get("TSAMD_EXCHANGE", "auto").lower()
-    if forced in ("rccl", "p2p"):
-        return forced, {}
+    modes = [forced] if forced in ("rccl", "p2p") else ["rccl", "p2p"]
     l = 32
+    sb, sc = shard
     beta = np.random.default_rng(7).uniform(0.05, 0.95, size=(l, k))
     locs = np.random.default_rng(8).integers(0, l, size=260).astype(np.uint32)
     locs[:6] = [3, 1, 3, 7, 0, 5]
-    out, rate = {}, {}
-    for mode in ("rccl", "p2p"):
-        out[mode] = None
+    report = {"updates_per_s": {}, "rel_err_vs_oracle": {}, "valid": {}}
+    final, want = {}, None
+    for mode in modes:
+        final[mode] = None
+        report["valid"][mode] = False
         e = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
         try:
             e.synth_genotypes(theta_shard, beta, seed=11)
-            e.set_gamma(gamma_shard)
+            e.set_gamma(gamma_full[sb:sb + sc])
             try:
                 (tdist.bootstrap_p2p if mode == "p2p" else tdist.bootstrap_comm)(e, dist)
             except Exception as exc:  # noqa: BLE001 -- raised on every rank together
                 if rank == 0:
                     print(f"[bench] exchange self-test, {mode}: {exc}", file=sys.stderr, flush=True)
                 continue
-            res, err, dt = None, None, 0.0
+            if want is None:  # the oracle's answer for the first 6 updates, once, on rank 0
+                cols = np.stack([e.download_bed(j) for j in range(l)])          # [l][shard bytes]
+                parts = gather_bytes(cols, dist, rank)
+                if rank == 0:
+                    orc = op.Oracle(n, l, k, nthreads=cores)
+                    orc.load_bed_payload(np.concatenate(parts, axis=1)[:, :(n + 3) // 4])
+                    orc.set_gamma(gamma_full)
+                    for loc in locs[:6]:
+                        orc.snp_update(int(loc))
+                    want = (orc.lambda_(), orc.gamma(), orc.c_indiv())
+                    orc.close()
+                else:
+                    want = ()
+            res, err, dt, e6 = None, None, 0.0, float("inf")
             try:
-                e.run_schedule(locs[:60])
+                e.run_schedule(locs[:6])
+                e.synchronize()
+                lam6 = e.get_lambda()
+                gam6 = tdist.gather_rows(e.get_gamma(), n, dist, ts.shard_range)
+                cnt6 = tdist.gather_rows(e.get_counts().astype(np.float64)[:, None], n, dist, ts.shard_range)[:, 0]
+                if rank == 0:
+                    e6 = max(rel_err(lam6, want[0]), rel_err(gam6, want[1]))
+                    if not np.array_equal(cnt6, want[2]):
+                        e6 = float("inf")
+                e.run_schedule(locs[6:60])
                 e.synchronize()
                 dist.barrier()
                 t0 = time.perf_counter()
@@ -106,27 +145,40 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
                 res = (e.get_lambda(), e.get_gamma())
             except Exception as exc:  # noqa: BLE001
                 err = exc
+            t6 = torch.tensor([e6 if rank == 0 else 0.0], dtype=torch.float64)
+            dist.broadcast(t6, src=0)
+            e6 = float(t6.item())
+            report["rel_err_vs_oracle"][mode] = e6 if np.isfinite(e6) else None
             if tdist.all_ok(err is None, dist):
-                out[mode] = res
                 tt = torch.tensor([dt], dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                rate[mode] = round((len(locs) - 60) / float(tt.item()), 1)
+                report["updates_per_s"][mode] = round((len(locs) - 60) / float(tt.item()), 1)
+                if e6 < SELFTEST_TOL:
+                    final[mode] = res
+                    report["valid"][mode] = True
             elif rank == 0:
                 print(f"[bench] exchange self-test, {mode}: run failed ({err})", file=sys.stderr, flush=True)
         finally:
             dist.barrier()
             e.close()
             dist.barrier()
-    ok = out["p2p"] is not None
-    if ok and out["rccl"] is not None:
-        ok = all(np.allclose(a, b_, rtol=1e-10, atol=0) for a, b_ in zip(out["rccl"], out["p2p"]))
-    ok = tdist.all_ok(ok, dist)
-    if ok and out["rccl"] is not None and rate["p2p"] < rate["rccl"]:  # (rates are identical on every rank)
-        ok = False
+    if final.get("p2p") is not None and final.get("rccl") is not None:
+        d = max(rel_err(a, b_) for a, b_ in zip(final["p2p"], final["rccl"]))
+        td = torch.tensor([d], dtype=torch.float64)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        report["p2p_vs_rccl_rel_err_260_updates"] = float(td.item())
+        if float(td.item()) > 1e-8:  # they disagree although both matched the oracle early on: trust neither
+            report["valid"]["p2p"] = report["valid"]["rccl"] = False
+    rates = report["updates_per_s"]
+    chosen = None
+    if report["valid"].get("p2p") and (not report["valid"].get("rccl") or rates["p2p"] >= rates["rccl"]):
+        chosen = "p2p"
+    elif report["valid"].get("rccl"):
+        chosen = "rccl"
+    report["chosen"] = chosen
     if rank == 0:
-        print(f"[bench] exchange self-test: updates/s {rate}, p2p valid {out['p2p'] is not None} -> "
-              f"{'p2p' if ok else 'rccl'}", file=sys.stderr, flush=True)
-    return ("p2p" if ok else "rccl"), rate
+        print(f"[bench] exchange self-test: {json.dumps(report)}", file=sys.stderr, flush=True)
+    return chosen, report
 
 
 def main():
@@ -141,12 +193,29 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    # The oracle (the checker: cpu_baseline leg, exchange self-test) is loaded -- and built if the
+    # library is missing -- BEFORE anything initialises the GPU: no child process may be started
+    # from a process that has.
+    cores = args.cpu_threads or usable_cores()
+    oracle_ok = True
+    if rank == 0 and (world > 1 or args.cpu_seconds > 0):
+        try:
+            import oracle_py as op
+
+            op.lib()
+        except Exception as exc:  # noqa: BLE001
+            oracle_ok = False
+            print(f"[bench] oracle library unavailable ({exc})", file=sys.stderr, flush=True)
+
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        fail_together(oracle_ok, dist, "the exchange self-test needs oracle/libts_oracle.so on rank 0")
+
+    import torch
 
     import terastructure_amd as ts
 
@@ -162,8 +231,6 @@ def main():
     reserve = 4 * (sc * k * 8) + (6 << 30)          # w, gamma, synth scratch + headroom
     l = int(min(args.l, max(64, (free_b - reserve) // per_loc)))
     if dist is not None:
-        import torch
-
         t = torch.tensor([l], dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         l = int(t.item())
@@ -172,31 +239,40 @@ def main():
     # synthetic PSD data: theta ~ Dir(0.2), beta ~ U(0.05, 0.95), y ~ Bin(2, theta.beta)
     rng = np.random.default_rng(args.seed)
     theta = rng.dirichlet(np.full(k, 0.2), size=n)[sb:sb + sc]
-    gamma0 = np.random.default_rng(args.seed + 2).gamma(100.0, 0.01, size=(n, k))[sb:sb + sc]
-    exchange, exchange_rates = "none", {}
+
+    def gamma_init():
+        return np.random.default_rng(args.seed + 2).gamma(100.0, 0.01, size=(n, k))
+
+    gamma0 = gamma_init()
+    exchange, exchange_report = "none", {}
     if world > 1:
-        exchange, exchange_rates = choose_exchange(ts, dist, rank, world, local_rank, n, k, theta, gamma0)
+        exchange, exchange_report = choose_exchange(ts, dist, rank, world, local_rank, n, k, theta, gamma0, (sb, sc),
+                                                    cores)
+        # an exchange that did not reproduce the oracle is never timed
+        fail_together(exchange is not None, dist,
+                      f"no exchange passed its self-test on this node: {json.dumps(exchange_report)}")
     eng = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
     if world > 1:
         from terastructure_amd import dist as tdist
 
-        if exchange == "p2p":
-            tdist.bootstrap_p2p(eng, dist)
-        else:
-            tdist.bootstrap_comm(eng, dist)
+        err = None
+        try:
+            (tdist.bootstrap_p2p if exchange == "p2p" else tdist.bootstrap_comm)(eng, dist)
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+        fail_together(err is None, dist, f"exchange bootstrap: {err}")
 
     chunk = 1 << 17
     brng = np.random.default_rng(args.seed + 1)
     for l0 in range(0, l, chunk):
         beta = brng.uniform(0.05, 0.95, size=(min(chunk, l - l0), k))
         eng.synth_genotypes(theta, beta, first_loc=l0, seed=args.seed)
-    eng.set_gamma(gamma0)
+    eng.set_gamma(gamma0[sb:sb + sc])
     del theta, gamma0
+    eng.prepare()  # graphs captured + instantiated here, not inside the timed region
     setup_s = time.time() - t_setup
 
     locs = np.random.default_rng(args.seed + 3).integers(0, l, size=args.warmup + args.steps).astype(np.uint32)
-
-    import torch
 
     def device_sync():
         eng.synchronize()                      # the engine's own stream (errors surface here)
@@ -207,23 +283,26 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    barrier()  # (peer-to-peer: a rank's kernels wait at most 3 s for a peer that has not started yet)
-    if args.warmup:
-        eng.run_schedule(locs[:args.warmup])
-    barrier()
-    p0 = eng.total_passes()
-    h0 = eng.pass_histogram()
-    t0 = time.perf_counter()
-    eng.run_schedule(locs[args.warmup:])
-    device_sync()
+    err, dt, passes, hist = None, 0.0, 0, None
+    try:
+        barrier()  # (peer-to-peer: a rank's kernels wait at most 3 s for a peer that has not started yet)
+        if args.warmup:
+            eng.run_schedule(locs[:args.warmup])
+        barrier()
+        p0 = eng.total_passes()
+        h0 = eng.pass_histogram()
+        t0 = time.perf_counter()
+        eng.run_schedule(locs[args.warmup:])
+        device_sync()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        passes = eng.total_passes() - p0
+        hist = eng.pass_histogram() - h0
+    except Exception as exc:  # noqa: BLE001 -- e.g. TSAMD_ECOMM after a peer timed out
+        err = exc
+    fail_together(err is None, dist, f"timed region: {err}")
     if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    passes = eng.total_passes() - p0
-    hist = eng.pass_histogram() - h0
-    if dist is not None:
-        import torch
-
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -231,8 +310,9 @@ def main():
     value = args.steps / dt
     mean_passes = passes / max(1, args.steps)
 
-    # ---- roofline of the dominant kernel (plain pass, ts_pass<KT,false>) ------------
-    # algorithmic bytes per launch = 8*N_shard*K (weights) + N_shard/4 (2-bit column)
+    # ---- roofline of the two pass kernels ------------------------------------------------
+    # plain pass (dominant: 9 of 10 launches): 8*N_shard*K (weights) + N_shard/4 (2-bit column)
+    # first pass (gamma step fused): R w, R gamma, W gamma, W w = 32*N*K; c_n R+W = 8N; two columns = N/2
     roofline = None
     if not args.no_profile:
         prof_steps = min(args.steps, 300)
@@ -245,29 +325,52 @@ def main():
             avg_s = pr["pass_ms"] / pr["pass_launches"] * 1e-3
             alg_bytes = 8.0 * sc * k + sc / 4.0
             achieved = alg_bytes / avg_s / 1e9
-            traffic = None
+            first_s = pr["first_ms"] / max(1, pr["first_launches"]) * 1e-3
+            first_bytes = 32.0 * sc * k + 8.0 * sc + sc / 2.0
+            first_achieved = first_bytes / first_s / 1e9
+            traffic = first_traffic = None
             pmc = os.path.join(ROOT, "profiles", "pass_kernel_pmc.json")
             if os.path.exists(pmc):
                 try:
                     rec = json.load(open(pmc))
                     if rec.get("n") == n and rec.get("k") == k and rec.get("n_gpus") == world:
                         traffic = rec.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+                        first_traffic = rec.get("first_pass_hbm_bytes_per_launch")
+                except Exception:  # noqa: BLE001
+                    pass
+            try:
+                read_us, rmw_us = eng.probe_stream(50)
+            except Exception as exc:  # noqa: BLE001 -- an extra, never fatal
+                read_us = rmw_us = None
+                print(f"[bench] stream probe skipped: {exc}", file=sys.stderr, flush=True)
             roofline = {
-                "bound": "hbm", "kernel": "ts_pass<KT,false>", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                "bound": "hbm", "kernel": "ts_pass<K,false> (plain pass, 9 of 10 launches per update)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_us": round(avg_s * 1e6, 3), "launches_timed": pr["pass_launches"],
-                "first_pass_avg_us": round(pr["first_ms"] / max(1, pr["first_launches"]) * 1e3, 3),
+                "ceiling_note": "fabric-side bandwidth incl. Infinity Cache, not DRAM bandwidth: the pass re-reads the "
+                                "same weights (8NK bytes: 64 MB at N=1M, K=8) every launch and they stay in the 256 MiB "
+                                "Infinity Cache; FETCH_SIZE counts those hits.  probe_read_us is a bare streaming read "
+                                "of the same array with the same geometry on this box (tsamd_probe_stream): the "
+                                "second denominator.",
+                "probe_read_us": None if read_us is None else round(read_us, 3),
+                "frac_of_probe": None if read_us is None else round(read_us * 1e-6 / avg_s, 4),
+                "first_pass": {
+                    "kernel": "ts_pass<K,true> (first pass of a SNP + the previous SNP's gamma step, 1 of 10 launches)",
+                    "bound": "hbm", "achieved": round(first_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(first_achieved / HBM_PEAK_GBS, 4), "traffic": first_traffic,
+                    "algorithmic_bytes_per_launch": first_bytes, "avg_launch_us": round(first_s * 1e6, 3),
+                    "launches_timed": pr["first_launches"],
+                    "probe_rmw_us": None if rmw_us is None else round(rmw_us, 3),
+                    "frac_of_probe": None if rmw_us is None else round(rmw_us * 1e-6 / first_s, 4),
+                },
             }
 
-    # second denominator: what a plain device-to-device copy reaches on this box,
+    # third denominator: what a plain device-to-device copy reaches on this box,
     # with the benchmark's data still resident (read + write bytes over the copy time)
     if roofline is not None and world == 1:
         try:
-            import torch
-
             dev = torch.device("cuda", local_rank)
             src = torch.empty(1 << 27, dtype=torch.float64, device=dev)  # 1 GiB
             dst = torch.empty_like(src)
@@ -286,38 +389,63 @@ def main():
             roofline["device_copy_GBps"] = None
             print(f"[bench] device copy probe skipped: {exc}", file=sys.stderr, flush=True)
 
-    # ---- CPU baseline: the oracle ("port") on the host cores, bounded sample ---------
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    # ---- CPU baseline: the oracle ("port") on the host cores, bounded sample; then the GPU ----
+    # ---- repeats exactly those updates from the same start and the two states are compared ----
+    cpu, parity = None, None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and oracle_ok:
         import oracle_py as op
 
-        cores = args.cpu_threads or usable_cores()
         ls = 8  # sample columns; per-update cost does not depend on L
-        orc = op.Oracle(n, ls, k, nthreads=cores, gamma_scale=float(l))
+        g0 = gamma_init()
         sample = np.stack([eng.download_bed(int(j)) for j in range(ls)])
-        orc.load_bed_payload(sample)
-        orc.set_gamma(np.random.default_rng(args.seed + 2).gamma(100.0, 0.01, size=(n, k)))
-        done, tc0 = 0, time.perf_counter()
-        orc.snp_update(0)  # untimed: first call has no gamma step to apply
-        tc0 = time.perf_counter()
-        while True:
-            orc.snp_update((done + 1) % ls)
-            done += 1
-            if time.perf_counter() - tc0 > args.cpu_seconds or done >= args.steps:
-                break
-        cdt = time.perf_counter() - tc0
+
+        def run_oracle(threads, budget, max_updates):
+            orc = op.Oracle(n, ls, k, nthreads=threads, gamma_scale=float(l))
+            orc.load_bed_payload(sample)
+            orc.set_gamma(g0)
+            seq = [0]
+            orc.snp_update(0)  # untimed: the first call has no gamma step to apply
+            done, tc0 = 0, time.perf_counter()
+            while True:
+                seq.append((done + 1) % ls)
+                orc.snp_update(seq[-1])
+                done += 1
+                if time.perf_counter() - tc0 > budget or done >= max_updates:
+                    break
+            return orc, seq, done, time.perf_counter() - tc0
+
+        orc, seq, done, cdt = run_oracle(cores, args.cpu_seconds * 0.75, args.steps)
+        want = (orc.lambda_(), orc.gamma(), orc.c_indiv())
+        orc.close()
+        orc1, _, done1, cdt1 = run_oracle(1, args.cpu_seconds * 0.25, 4)
+        orc1.close()
         cpu = {"value": round(done / cdt, 4), "unit": "SNP-minibatch updates/s", "cores": cores,
-               "kind": "port",
+               "kind": "port", "value_1_thread": round(done1 / cdt1, 4),
                "sample": f"{done} updates (10 passes + gamma step each) at N={n}, K={k} on {ls} of the "
                          f"benchmark's own columns, oracle/ts_oracle.c with {cores} OpenMP threads "
                          f"in the reference's work partition (host shows {os.cpu_count()} CPUs, "
-                         f"{cores} usable under its affinity mask / cgroup quota)"}
-        orc.close()
+                         f"{cores} usable under its affinity mask / cgroup quota); value_1_thread: "
+                         f"{done1} updates with one thread"}
+        # the same updates on the GPU, from the same state (lambda of the sample columns back to
+        # eta, gamma and c_n back to the start, no pending step), through the timed entry point
+        eta = np.ones((k, 2))
+        for j in range(ls):
+            eng.set_lambda(j, eta)
+        eng.set_gamma(g0)
+        eng.set_counts(np.zeros(n, dtype=np.uint32))
+        eng.clear_pending()
+        eng.run_schedule(np.array(seq, dtype=np.uint32))
+        eng.synchronize()
+        e_lam = rel_err(eng.get_lambda(0, ls), want[0])
+        e_gam = rel_err(eng.get_gamma(), want[1])
+        cnt_eq = bool(np.array_equal(eng.get_counts(), want[2]))
+        parity = {"lambda_rel_err": e_lam, "gamma_rel_err": e_gam, "c_n_equal": cnt_eq, "updates": len(seq),
+                  "tolerance": 1e-9, "ok": bool(e_lam < 1e-9 and e_gam < 1e-9 and cnt_eq)}
 
     if rank == 0:
         alg_update = (mean_passes + 4) * 8.0 * n * k + (mean_passes + 1) * n / 4.0 + 8.0 * n
         out = {
-            "metric": "SNP-minibatch updates/sec (N x K phi+accum) at N=1M K=8",
+            "metric": f"SNP-minibatch updates/sec (N x K phi+accum) at N={n} K={k}",
             "value": round(value, 2), "unit": "updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
@@ -326,20 +454,22 @@ def main():
                                    f"HBM-resident, individuals sharded over {world} GPU(s)",
                        "n": n, "l": l, "k": k, "l_requested": args.l,
                        "parallelism": f"individual-shard x{world}", "exchange": exchange,
-                       "exchange_selftest_updates_per_s": exchange_rates},
+                       "exchange_selftest": exchange_report},
             "mean_inner_passes": round(mean_passes, 3),
             "inner_passes_histogram": {str(i): int(c) for i, c in enumerate(hist) if c},
             "nk_pass_per_s": round(value * mean_passes * n * k, 1),
             "update_algorithmic_bytes": alg_update,
             "update_hbm_frac_of_peak": round(alg_update * value / (world * HBM_PEAK_GBS * 1e9), 4),
             "setup_s": round(setup_s, 1),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_baseline": parity,
         }
         print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        sys.exit("bench.py: GPU state differs from the CPU baseline's on the same updates: " + json.dumps(parity))
 
 
 if __name__ == "__main__":

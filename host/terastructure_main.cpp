@@ -532,23 +532,31 @@ void save_model(Run &r) {
 bool compute_likelihood(Run &r, bool first) {
   uint32_t k = 0;
   double s = .0;
-  size_t sz = 0;
-  for (auto &kv : r.validation) {
-    const uint32_t loc = kv.first;
-    printf("\rdone:%.2f%%", ((double)sz / r.validation.size()) * 100);
-    if (!first) {  // snp_likelihood: optimize_lambda(loc) in hol mode, then _iter++
-      run_all(r, &loc, 1, 1);
-      r.iter++;
-    }
-    for (tsamd_ctx *cx : r.ctxs) {  // ascending individuals: shard after shard
-      double u = 0;
-      uint32_t c = 0;
-      TS(r, tsamd_heldout_loglik(cx, loc, &u, &c));
-      s += u;
-      k += c;
-    }
-    sz++;
+  // The whole block at once (tsamd_heldout_eval): theta is frozen while it runs, so the
+  // reference's "per location: optimize_lambda in hol mode, _iter++, held-out sum" is one
+  // hol-mode schedule over the validation locations (ascending, the map's order) followed by
+  // one evaluation kernel per shard; the sums are then added in the reference's order.
+  std::vector<uint32_t> locs;
+  locs.reserve(r.validation.size());
+  for (auto &kv : r.validation) locs.push_back(kv.first);
+  const uint32_t nl = (uint32_t)locs.size();
+  if (!first && nl) {  // snp_likelihood: optimize_lambda(loc) in hol mode, then _iter++
+    run_all(r, locs.data(), nl, 1);
+    r.iter += nl;
   }
+  std::vector<std::vector<double>> sums(r.ctxs.size(), std::vector<double>(nl));
+  std::vector<std::vector<uint32_t>> cnts(r.ctxs.size(), std::vector<uint32_t>(nl));
+  for (size_t i = 0; i < r.ctxs.size(); ++i) {
+    r.ctx = r.ctxs[i];
+    TS(r, tsamd_heldout_eval(r.ctxs[i], locs.data(), nl, 0, sums[i].data(), cnts[i].data(), nullptr, nullptr));
+  }
+  r.ctx = r.ctxs[0];
+  for (uint32_t j = 0; j < nl; ++j)
+    for (size_t i = 0; i < r.ctxs.size(); ++i) {  // ascending individuals: shard after shard
+      s += sums[i][j];
+      k += cnts[i][j];
+    }
+  printf("\rdone:%.2f%%", 100.0);
   fprintf(r.vf, "%d\t%d\t%.9f\t%d\t%f\n", r.iter, r.duration(), (s / k), k, exp(s / k));
   fflush(r.vf);
   const double a = s / k;

@@ -121,6 +121,11 @@ int tsamd_snp_update(tsamd_ctx *ctx, uint32_t loc, int hol_mode, uint32_t *inner
  * asynchronous: returns after enqueueing, tsamd_synchronize() waits. */
 int tsamd_run_schedule(tsamd_ctx *ctx, const uint32_t *locs, uint32_t n, int hol_mode);
 int tsamd_synchronize(tsamd_ctx *ctx);
+/* optional: capture and instantiate, now, the hipGraphs tsamd_run_schedule replays (sequences of
+ * 16, 8, 4, 2 and 1 SNPs; a schedule of any length is their binary decomposition), so that the
+ * first tsamd_run_schedule call does not pay for it.  Otherwise that call does it.  On a sharded
+ * context call it after the exchange has been set up (tsamd_comm_init / tsamd_p2p_connect). */
+int tsamd_prepare(tsamd_ctx *ctx);
 /* total inner passes executed by tsamd_run_schedule / snp_update calls since creation */
 int tsamd_total_passes(tsamd_ctx *ctx, uint64_t *passes);
 /* completed SNP updates since creation by the number of inner passes they ran: hist[i] for
@@ -135,6 +140,19 @@ int tsamd_clear_pending(tsamd_ctx *ctx);
  * held-out individuals of loc in this shard: sum of log(max(C(2,y) q^y (1-q)^(2-y), 1e-30)),
  * q = sum_k Ebeta[loc][k] * Etheta[n][k]; ascending individual order. */
 int tsamd_heldout_loglik(tsamd_ctx *ctx, uint32_t loc, double *sum, uint32_t *count);
+/* replaces the validation block of compute_likelihood (src/snpsamplinge.cc:476-498:
+ * for every validation location, snp_likelihood = optimize_lambda(loc) in hol mode, then the
+ * held-out sum) for n locations at once.  theta does not move inside that block (only the
+ * pending step of the last training SNP is applied, by the first update), so with run_updates != 0
+ * this is one tsamd_run_schedule(locs, n, hol_mode = 1) followed by ONE kernel over all
+ * (location, individual) entries of the context's device-resident held-out table -- no host
+ * round trip and no allocation per location.  run_updates == 0 only evaluates (e.g. the initial
+ * likelihood, :478 first == true; or after tsamd_run_schedule_all on several contexts).
+ * loc_sums / loc_counts ([n], may be NULL) get what tsamd_heldout_loglik returns for each
+ * location, bit for bit (entries are added in ascending individual order by one thread);
+ * sum / count = their totals added in the listed order. */
+int tsamd_heldout_eval(tsamd_ctx *ctx, const uint32_t *locs, uint32_t n, int run_updates, double *loc_sums,
+                       uint32_t *loc_counts, double *sum, uint32_t *count);
 
 /* ---- multi-GPU: individuals sharded, lambda_t all-reduced per pass over RCCL ----
  * rank 0 calls tsamd_comm_unique_id and ships the bytes to every rank (any
@@ -184,10 +202,19 @@ int tsamd_synth_genotypes(tsamd_ctx *ctx, const double *theta, const double *bet
 /* HIP-event timing of the kernels issued by tsamd_run_schedule (eager launches while
  * enabled): per SNP one event pair brackets the first-pass kernel and one brackets the run
  * of max_inner-1 plain-pass launches.  Enable, run, then read launch counts and summed
- * bracket durations (a plain-pass bracket includes its inter-kernel gaps). */
+ * bracket durations (a plain-pass bracket includes its inter-kernel gaps).  pass_launches
+ * counts the plain passes that really swept (the near-empty launches after an early
+ * convergence stay inside the bracket's time but are not counted). */
 int tsamd_profile_enable(tsamd_ctx *ctx, int on);
 int tsamd_profile_read(tsamd_ctx *ctx, uint64_t *pass_launches, double *pass_ms_total,
                        uint64_t *first_launches, double *first_ms_total);
+/* On-box ceilings for the two pass kernels, measured on the context's own arrays and launch
+ * geometry with the run's data resident: read_us = one bare streaming read of the weights (K
+ * rows of 16-byte loads, alternating sweep direction: the plain pass' traffic minus the 2-bit
+ * column), rmw_us = one bare read-modify-write of weights and gamma (the first pass' traffic;
+ * the values are written back unchanged).  Averages over reps launches (HIP events).  The
+ * wide-K fallback (k > TSAMD_SPECIALIZED_K) is probed with the same two kernels. */
+int tsamd_probe_stream(tsamd_ctx *ctx, uint32_t reps, double *read_us, double *rmw_us);
 /* device memory in bytes currently free / total on the context's device */
 int tsamd_mem_info(tsamd_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 

@@ -56,10 +56,12 @@ SYMBOLS = {
     "tsamd_snp_update": (_int, [_vp, _u32, _int, _pu32]),
     "tsamd_run_schedule": (_int, [_vp, _pu32, _u32, _int]),
     "tsamd_synchronize": (_int, [_vp]),
+    "tsamd_prepare": (_int, [_vp]),
     "tsamd_total_passes": (_int, [_vp, _pu64]),
     "tsamd_pass_histogram": (_int, [_vp, _pu64]),
     "tsamd_clear_pending": (_int, [_vp]),
     "tsamd_heldout_loglik": (_int, [_vp, _u32, _pd, _pu32]),
+    "tsamd_heldout_eval": (_int, [_vp, _pu32, _u32, _int, _pd, _pu32, _pd, _pu32]),
     "tsamd_comm_unique_id": (_int, [_pu8]),
     "tsamd_comm_init": (_int, [_vp, _pu8]),
     "tsamd_p2p_export": (_int, [_vp, _pu8]),
@@ -69,6 +71,7 @@ SYMBOLS = {
     "tsamd_synth_genotypes": (_int, [_vp, _pd, _pd, _u32, _u32, _u64, _dbl]),
     "tsamd_profile_enable": (_int, [_vp, _int]),
     "tsamd_profile_read": (_int, [_vp, _pu64, _pd, _pu64, _pd]),
+    "tsamd_probe_stream": (_int, [_vp, _u32, _pd, _pd]),
     "tsamd_mem_info": (_int, [_vp, _pu64, _pu64]),
 }
 

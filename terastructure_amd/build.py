@@ -17,8 +17,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libtsamd.so")
 MAX_K = 32
-HEADERS = [os.path.join(CSRC, "tsamd_kernels.h"), os.path.join(CSRC, "tsamd_generic_kernels.h"), os.path.join(CSRC, "tsamd_device.h"),
-           os.path.join(ROOT, "include", "tsamd.h")]
+HEADERS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(ROOT, "include", "tsamd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("TSAMD_EXTRA_HIPCC_FLAGS", "").split()
 

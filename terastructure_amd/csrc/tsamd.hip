@@ -71,7 +71,13 @@ struct HeldLoc {
 };
 
 constexpr uint32_t kProfCap = 8192;
-constexpr uint32_t kGraphSnps = 16;  // SNPs per captured graph
+constexpr uint32_t kGraphLevels = 5;                     // captured graphs of 1, 2, 4, 8 and 16 SNPs ...
+constexpr uint32_t kGraphSnps = 1u << (kGraphLevels - 1);  // ... so that any schedule length replays without padding
+
+struct GraphSlot {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
 
 }  // namespace
 
@@ -88,21 +94,34 @@ struct tsamd_ctx {
   uint8_t *h_stage = nullptr;  // pinned staging for uploads
   size_t stage_bytes = 0;
   std::map<uint32_t, HeldLoc> held;
+  // flat device copy of the held-out table (ids + true genotypes, locations ascending), rebuilt
+  // lazily after tsamd_set_heldout / a re-upload; spans index it by location
+  bool held_dirty = true;
+  std::map<uint32_t, std::pair<uint64_t, uint32_t>> held_span;
+  uint32_t *d_hids = nullptr;
+  uint8_t *d_hy = nullptr;
+  double *d_hterms = nullptr;
+  size_t held_cap = 0;
+  HeldReq *d_hreq = nullptr;
+  double *d_hsums = nullptr;
+  size_t hreq_cap = 0;
   ncclComm_t comm = nullptr;
   Xchg *xchg = nullptr;                    // peer-to-peer exchange buffer (fine-grained, IPC-exported)
   std::vector<void *> peer_maps;           // hipIpcOpenMemHandle results to close
   bool p2p = false;
   bool split = false;  // lambda_t leaves the pass via ctl->lt and the epilogue is its own kernel
+  bool rccl_graph = false;  // TSAMD_RCCL_GRAPH=1: capture the RCCL all-reduce into the replayed graphs
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev_pass, ev_first;  // start/stop pairs
   uint32_t n_ev_pass = 0, n_ev_first = 0;
   uint64_t prof_pass_n = 0, prof_first_n = 0;
+  uint64_t prof_passes0 = 0;  // ctl->total_passes when profiling was enabled
+  bool prof_capped = false;   // more SNPs than event pairs: not every bracket was timed
   double prof_pass_ms = 0, prof_first_ms = 0;
-  // hipGraph replay of the per-SNP kernel sequence
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  uint32_t graph_snps = 0, graph_par0 = 0;
+  // hipGraph replay of the per-SNP kernel sequence: [log2 SNPs][launch parity on entry]
+  GraphSlot graphs[kGraphLevels][2];
+  bool graphs_ready = false;
   uint64_t q = 0;  // kernels of the state-machine sequence launched so far (parity = q & 1)
   uint32_t prev_rows = 0;  // grid of the last pass kernel enqueued (row-count hint for the next)
   std::vector<std::vector<uint32_t>> keepalive;  // host schedules of copies possibly still in flight
@@ -160,22 +179,25 @@ __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
 // Every kernel of the state-machine sequence gets the next parity bit (tsamd_device.h).
 uint32_t next_parity(tsamd_ctx *c) { return (uint32_t)(c->q++ & 1u); }
 
-// one pass = ts_pass [+ ts_reduce_rows + all-reduce when sharded]
-int enqueue_pass(tsamd_ctx *c, bool first) {
+// one pass = ts_pass [+ ts_reduce_rows + all-reduce when sharded]; `pass` = its index within
+// the SNP (0 = first pass).  Odd plain passes sweep backwards (bit 1 of the parity argument).
+int enqueue_pass(tsamd_ctx *c, uint32_t pass) {
+  const bool first = pass == 0;
   const uint32_t par = next_parity(c);
+  const uint32_t par_arg = par | ((pass & 1u) << 1);
   // rows of the previous launch of the sequence: a first pass follows a plain pass (or a
   // kernel that left nothing pending), a plain pass follows the first pass or a plain pass
   const uint32_t hint = c->prev_rows;
   if (c->wide) {
     if (first)
-      hipLaunchKernelGGL((ts_pass_wide<true>), dim3(c->grid_first), dim3(kWideBlock), 0, c->stream, c->p, par, hint);
+      hipLaunchKernelGGL((ts_pass_wide<true>), dim3(c->grid_first), dim3(kWideBlock), 0, c->stream, c->p, par_arg, hint);
     else
-      hipLaunchKernelGGL((ts_pass_wide<false>), dim3(c->grid_first), dim3(kWideBlock), 0, c->stream, c->p, par, hint);
+      hipLaunchKernelGGL((ts_pass_wide<false>), dim3(c->grid_first), dim3(kWideBlock), 0, c->stream, c->p, par_arg, hint);
     c->prev_rows = c->grid_first;
   } else if (first)
-    kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p, par, hint);
+    kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p, par_arg, hint);
   else
-    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p, par, hint);
+    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p, par_arg, hint);
   if (!c->wide) c->prev_rows = first ? c->grid_first : c->grid;
   if (c->split && !c->p2p) {  // (peer-to-peer: every workgroup has already pushed its row to every rank)
     hipLaunchKernelGGL(ts_reduce_rows, dim3(1), dim3(256), 0, c->stream, c->p, par);
@@ -193,7 +215,7 @@ int enqueue_pass(tsamd_ctx *c, bool first) {
 }
 
 void enqueue_begin(tsamd_ctx *c, uint32_t n, bool drop_pending) {
-  hipLaunchKernelGGL(ts_begin, dim3(1), dim3(256), 0, c->stream, c->p.ctl, n, next_parity(c), 2 * c->cfg.k,
+  hipLaunchKernelGGL(ts_begin, dim3(1), dim3(256), 0, c->stream, c->p, (const uint32_t *)c->d_sched, n, next_parity(c),
                      drop_pending ? 1u : 0u);
 }
 
@@ -219,12 +241,13 @@ int prof_event(tsamd_ctx *c, std::vector<hipEvent_t> &evs, uint32_t slot, hipEve
 
 int enqueue_snp(tsamd_ctx *c) {
   const bool prof = c->prof && c->n_ev_first < kProfCap;
+  if (c->prof && !prof) c->prof_capped = true;
   hipEvent_t e = nullptr;
   if (prof) {
     if (int rc = prof_event(c, c->ev_first, 2 * c->n_ev_first, &e)) return rc;
     HIP_TRY(c, hipEventRecord(e, c->stream));
   }
-  int rc = enqueue_pass(c, true);
+  int rc = enqueue_pass(c, 0);
   if (prof) {
     if (int rc2 = prof_event(c, c->ev_first, 2 * c->n_ev_first + 1, &e)) return rc2;
     HIP_TRY(c, hipEventRecord(e, c->stream));
@@ -234,7 +257,7 @@ int enqueue_snp(tsamd_ctx *c) {
       HIP_TRY(c, hipEventRecord(e, c->stream));
     }
   }
-  for (uint32_t i = 1; rc == TSAMD_OK && i < c->cfg.max_inner; ++i) rc = enqueue_pass(c, false);
+  for (uint32_t i = 1; rc == TSAMD_OK && i < c->cfg.max_inner; ++i) rc = enqueue_pass(c, i);
   if (prof && c->cfg.max_inner > 1 && rc == TSAMD_OK) {
     if (int rc2 = prof_event(c, c->ev_pass, 2 * c->n_ev_pass + 1, &e)) return rc2;
     HIP_TRY(c, hipEventRecord(e, c->stream));
@@ -244,33 +267,75 @@ int enqueue_snp(tsamd_ctx *c) {
 }
 
 void destroy_graph(tsamd_ctx *c) {
-  if (c->graph_exec) hipGraphExecDestroy(c->graph_exec);
-  if (c->graph) hipGraphDestroy(c->graph);
-  c->graph_exec = nullptr;
-  c->graph = nullptr;
-  c->graph_snps = 0;
+  for (auto &lvl : c->graphs)
+    for (GraphSlot &g : lvl) {
+      if (g.exec) hipGraphExecDestroy(g.exec);
+      if (g.graph) hipGraphDestroy(g.graph);
+      g.exec = nullptr;
+      g.graph = nullptr;
+    }
+  c->graphs_ready = false;
 }
 
-// capture `snps` consecutive SNP sequences; kernels read everything that varies
-// (location, pending state) from device memory, so the graph is replayable as is.
-int build_graph(tsamd_ctx *c, uint32_t snps) {
-  destroy_graph(c);
-  c->graph_par0 = (uint32_t)(c->q & 1u);  // kernel arguments (parity bits) are frozen at capture
-  c->prev_rows = c->grid;                 // in replay the first kernel follows a plain pass (or nothing pending)
+// kernels of the state-machine sequence per SNP (ts_reduce_rows shares its pass' parity)
+uint32_t kernels_per_snp(const tsamd_ctx *c) { return c->cfg.max_inner; }
+
+// Capture 2^level consecutive SNP sequences for launch parity par0 on entry.  Kernels read
+// everything that varies (location, pending state) from device memory; the only frozen
+// arguments are the parity / sweep-direction bits, which is why a graph exists per entry parity.
+int build_graph(tsamd_ctx *c, uint32_t level, uint32_t par0) {
+  GraphSlot &slot = c->graphs[level][par0];
+  const uint64_t q_save = c->q;
+  const uint32_t rows_save = c->prev_rows;
+  c->q = par0;
+  // in replay the first kernel follows the last kernel of a SNP sequence (or nothing pending)
+  c->prev_rows = c->cfg.max_inner > 1 ? c->grid : c->grid_first;
   HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = TSAMD_OK;
-  for (uint32_t s = 0; s < snps && rc == TSAMD_OK; ++s) rc = enqueue_snp(c);
+  for (uint32_t s = 0; s < (1u << level) && rc == TSAMD_OK; ++s) rc = enqueue_snp(c);
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(c->stream, &g);
+  c->q = q_save;
+  c->prev_rows = rows_save;
   if (rc != TSAMD_OK) {
     if (g) hipGraphDestroy(g);
     return rc;
   }
   if (e != hipSuccess) return fail(c, TSAMD_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-  c->graph = g;
-  HIP_TRY(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
-  c->graph_snps = snps;
+  slot.graph = g;
+  HIP_TRY(c, hipGraphInstantiate(&slot.exec, slot.graph, nullptr, nullptr, 0));
   return TSAMD_OK;
+}
+
+// All graphs at once (10 captures, 62 SNP sequences): whatever the first schedule's length is,
+// no later call pays for a capture or an instantiation.
+int build_all_graphs(tsamd_ctx *c) {
+  if (c->graphs_ready) return TSAMD_OK;
+  for (uint32_t level = 0; level < kGraphLevels; ++level)
+    for (uint32_t par0 = 0; par0 < 2; ++par0)
+      if (!c->graphs[level][par0].exec)
+        if (int rc = build_graph(c, level, par0)) return rc;
+  c->graphs_ready = true;
+  return TSAMD_OK;
+}
+
+bool graphs_allowed(const tsamd_ctx *c) {
+  // (RCCL all-reduce inside the captured sequence: opt-in, TSAMD_RCCL_GRAPH=1 on every rank)
+  const bool comm_graph = c->comm && !c->p2p && c->rccl_graph;
+  return !(c->cfg.flags & TSAMD_FLAG_NO_GRAPH) && (!c->comm || c->p2p || comm_graph) && !c->prof;
+}
+
+// the graphs are built on first use; with an RCCL all-reduce inside, the first collective runs
+// outside the capture (RCCL sets its channels up lazily)
+int ensure_graphs(tsamd_ctx *c) {
+  if (c->graphs_ready) return TSAMD_OK;
+  if (c->comm && !c->p2p && c->rccl_graph) {
+    ncclResult_t r = g_rccl.AllReduce(c->p.ctl->lt[0], c->p.ctl->lt_sum[0], 2 * c->cfg.k, ncclDouble, ncclSum, c->comm,
+                                      c->stream);
+    if (r != ncclSuccess) return fail(c, TSAMD_ECOMM, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return build_all_graphs(c);
 }
 
 uint32_t env_u32(const char *name, uint32_t dflt) {
@@ -323,6 +388,8 @@ void activate_xchg(tsamd_ctx *c) {
   c->p.xchg_world = c->cfg.world;
   c->p.xchg_rank = c->cfg.rank;
   c->p.rows_from_lt = 0u;
+  c->p.xchg_test_delay = env_u32("TSAMD_TEST_XCHG_DELAY_US", 0) * 100u;  // test hooks (tsamd_device.h)
+  c->p.xchg_test_noguard = env_u32("TSAMD_TEST_XCHG_NOGUARD", 0);
   c->split = true;
   c->p2p = true;
   configure_launch(c, std::max<uint32_t>(16u, std::min<uint32_t>(kXchgBlocks, 512u / c->cfg.world)));
@@ -432,6 +499,11 @@ void tsamd_destroy(tsamd_ctx *c) {
   hipFree(c->p.ctl);
   hipFree(c->p.partials);
   hipFree(c->d_sched);
+  hipFree(c->d_hids);
+  hipFree(c->d_hy);
+  hipFree(c->d_hterms);
+  hipFree(c->d_hreq);
+  hipFree(c->d_hsums);
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -521,7 +593,6 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   CREATE_TRY(hipMalloc((void **)&p.partials, (size_t)2 * kMaxGrid * 2 * TSAMD_MAX_K * sizeof(double)));
   c->sched_cap = 1024;
   CREATE_TRY(hipMalloc((void **)&c->d_sched, c->sched_cap * sizeof(uint32_t)));
-  p.sched = c->d_sched;
 
   CREATE_TRY(hipMemsetAsync(p.bed, 0x55, L * p.colstride, c->stream));  // all missing
   CREATE_TRY(hipMemsetAsync(p.cnt, 0, np * sizeof(uint32_t), c->stream));
@@ -582,6 +653,7 @@ int tsamd_upload_bed(tsamd_ctx *c, const uint8_t *payload, uint64_t bytes_per_sn
   // a re-upload drops validation folds of those columns
   for (auto it = c->held.lower_bound(first_loc); it != c->held.end() && it->first < first_loc + n_locs;)
     it = c->held.erase(it);
+  c->held_dirty = true;
   return TSAMD_OK;
 }
 
@@ -602,6 +674,7 @@ int tsamd_set_heldout(tsamd_ctx *c, uint32_t loc, const uint32_t *indivs, uint32
   if (int rc = check_locs(c, loc, 1)) return rc;
   if (count && !indivs) return fail(c, TSAMD_EINVAL, "null indivs");
   HeldLoc &h = c->held[loc];
+  c->held_dirty = true;
   std::vector<uint32_t> ids;
   for (uint32_t i = 0; i < count; ++i) {
     if (indivs[i] >= c->cfg.n) return fail(c, TSAMD_EINVAL, "individual %u >= n", indivs[i]);
@@ -779,39 +852,45 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
     uint32_t cap = 1024;
     while (cap < n) cap *= 2;
     HIP_TRY(c, hipMalloc((void **)&c->d_sched, (size_t)cap * sizeof(uint32_t)));
-    c->sched_cap = cap;
-    if (c->p.sched != c->d_sched) destroy_graph(c);  // captured kernel arguments hold the old pointer
-    c->p.sched = c->d_sched;
+    c->sched_cap = cap;  // (the kernels take the pointer from Ctl, written by ts_begin)
   }
   HIP_TRY(c, hipMemcpyAsync(c->d_sched, ent.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   c->keepalive.push_back(std::move(ent));  // until the next tsamd_synchronize
+  // Everything that varies per SNP is read from device memory, so captured sequences of
+  // 16, 8, 4, 2 and 1 SNPs are replayed as often as the schedule length needs (binary
+  // decomposition: nothing is padded); results are identical to eager launches bit for bit.
+  const bool use_graph = graphs_allowed(c);
+  if (use_graph)
+    if (int rc = ensure_graphs(c)) return rc;
   enqueue_begin(c, n, false);
-  // Everything that varies per SNP is read from device memory, so one captured sequence
-  // of kGraphSnps SNPs is replayed as often as needed; kernels past the end of the
-  // schedule only carry the state forward.  (kGraphSnps is even, so a replay keeps the
-  // launch parity.)
-  // (RCCL all-reduce inside the captured sequence: opt-in, TSAMD_RCCL_GRAPH=1 on every rank)
-  const bool comm_graph = c->comm && !c->p2p && env_u32("TSAMD_RCCL_GRAPH", 0) != 0u;
-  const bool use_graph = !(c->cfg.flags & TSAMD_FLAG_NO_GRAPH) && (!c->comm || c->p2p || comm_graph) && !c->prof &&
-                         n >= kGraphSnps;
   if (use_graph) {
-    if (!c->graph_exec) {
-      if (comm_graph) {  // first collective outside the capture: RCCL sets its channels up lazily
-        ncclResult_t r = g_rccl.AllReduce(c->p.ctl->lt[0], c->p.ctl->lt_sum[0], 2 * c->cfg.k, ncclDouble, ncclSum, c->comm,
-                                          c->stream);
-        if (r != ncclSuccess) return fail(c, TSAMD_ECOMM, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t per_snp = kernels_per_snp(c);
+    uint32_t left = n;
+    for (int level = (int)kGraphLevels - 1; level >= 0; --level) {
+      const uint32_t snps = 1u << level;
+      while (left >= snps) {
+        HIP_TRY(c, hipGraphLaunch(c->graphs[level][c->q & 1u].exec, c->stream));
+        c->q += (uint64_t)snps * per_snp;
+        left -= snps;
       }
-      if (int rc = build_graph(c, kGraphSnps)) return rc;
     }
-    if ((uint32_t)(c->q & 1u) != c->graph_par0) enqueue_begin(c, 0xffffffffu, false);  // re-align parity
-    for (uint32_t i = 0; i < n; i += kGraphSnps) HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
+    c->prev_rows = c->cfg.max_inner > 1 ? c->grid : c->grid_first;
   } else {
     for (uint32_t i = 0; i < n; ++i)
       if (int rc = enqueue_snp(c)) return rc;
   }
   enqueue_flush(c);
   HIP_TRY(c, hipGetLastError());
+  return TSAMD_OK;
+}
+
+int tsamd_prepare(tsamd_ctx *c) {
+  CHECK_CTX(c);
+  HIP_TRY(c, hipSetDevice(c->dev));
+  if (c->cfg.world > 1 && !c->comm && !c->p2p) return TSAMD_OK;  // exchange not chosen yet: nothing to capture
+  if (!graphs_allowed(c)) return TSAMD_OK;
+  if (int rc = ensure_graphs(c)) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSAMD_OK;
 }
 
@@ -830,7 +909,7 @@ int tsamd_synchronize(tsamd_ctx *c) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, c->ev_pass[2 * i], c->ev_pass[2 * i + 1]) == hipSuccess) {
         c->prof_pass_ms += ms;
-        c->prof_pass_n += c->cfg.max_inner - 1;  // launches inside the bracket
+        c->prof_pass_n += c->cfg.max_inner - 1;  // launches inside the bracket (profile_read corrects for no-ops)
       }
     }
     for (uint32_t i = 0; i < c->n_ev_first; ++i) {
@@ -884,40 +963,99 @@ int tsamd_clear_pending(tsamd_ctx *c) {
   return TSAMD_OK;
 }
 
-int tsamd_heldout_loglik(tsamd_ctx *c, uint32_t loc, double *sum, uint32_t *count) {
+// flat device table of the held-out entries (persistent; no allocation per evaluation)
+static int sync_held_table(tsamd_ctx *c) {
+  if (!c->held_dirty) return TSAMD_OK;
+  size_t total = 0;
+  for (auto &kv : c->held) total += kv.second.local_ids.size();
+  std::vector<uint32_t> ids;
+  std::vector<uint8_t> ys;
+  ids.reserve(total);
+  ys.reserve(total);
+  c->held_span.clear();
+  for (auto &kv : c->held) {
+    if (kv.second.local_ids.empty()) continue;
+    c->held_span[kv.first] = {ids.size(), (uint32_t)kv.second.local_ids.size()};
+    ids.insert(ids.end(), kv.second.local_ids.begin(), kv.second.local_ids.end());
+    ys.insert(ys.end(), kv.second.ytrue.begin(), kv.second.ytrue.end());
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (total > c->held_cap) {
+    hipFree(c->d_hids);
+    hipFree(c->d_hy);
+    hipFree(c->d_hterms);
+    c->d_hids = nullptr, c->d_hy = nullptr, c->d_hterms = nullptr, c->held_cap = 0;
+    HIP_TRY(c, hipMalloc((void **)&c->d_hids, total * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_hy, total));
+    HIP_TRY(c, hipMalloc((void **)&c->d_hterms, total * sizeof(double)));
+    c->held_cap = total;
+  }
+  if (total) {
+    HIP_TRY(c, hipMemcpy(c->d_hids, ids.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_hy, ys.data(), total, hipMemcpyHostToDevice));
+  }
+  c->held_dirty = false;
+  return TSAMD_OK;
+}
+
+int tsamd_heldout_eval(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int run_updates, double *loc_sums,
+                       uint32_t *loc_counts, double *sum, uint32_t *count) {
   CHECK_CTX(c);
-  if (int rc = check_locs(c, loc, 1)) return rc;
   if (sum) *sum = 0.0;
   if (count) *count = 0;
-  auto it = c->held.find(loc);
-  if (it == c->held.end() || it->second.local_ids.empty()) return TSAMD_OK;
-  const HeldLoc &h = it->second;
-  const size_t m = h.local_ids.size();
+  if (n == 0) return TSAMD_OK;
+  if (!locs) return fail(c, TSAMD_EINVAL, "null locations");
+  for (uint32_t i = 0; i < n; ++i)
+    if (int rc = check_locs(c, locs[i], 1)) return rc;
   HIP_TRY(c, hipSetDevice(c->dev));
-  uint32_t *d_ids = nullptr;
-  uint8_t *d_y = nullptr;
-  double *d_out = nullptr;
-  HIP_TRY(c, hipMalloc((void **)&d_ids, m * sizeof(uint32_t)));
-  HIP_TRY(c, hipMalloc((void **)&d_y, m));
-  HIP_TRY(c, hipMalloc((void **)&d_out, m * sizeof(double)));
-  std::vector<double> terms(m);
-  hipError_t e = hipMemcpyAsync(d_ids, h.local_ids.data(), m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_y, h.ytrue.data(), m, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(ts_heldout_ll, dim3((m + 255) / 256), dim3(256), 0, c->stream, c->p.gam, c->npad, c->cfg.k,
-                       c->p.lam + (size_t)loc * 2 * c->cfg.k, d_ids, d_y, (uint32_t)m, d_out);
-    e = hipMemcpyAsync(terms.data(), d_out, m * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (run_updates)
+    if (int rc = tsamd_run_schedule(c, locs, n, 1)) return rc;
+  if (int rc = tsamd_synchronize(c)) return rc;
+  if (int rc = sync_held_table(c)) return rc;
+  std::vector<HeldReq> req;       // requested locations that have held-out entries in this shard
+  std::vector<uint32_t> req_of(n, 0xffffffffu);
+  for (uint32_t i = 0; i < n; ++i) {
+    auto it = c->held_span.find(locs[i]);
+    if (it == c->held_span.end()) continue;
+    req_of[i] = (uint32_t)req.size();
+    req.push_back(HeldReq{it->second.first, it->second.second, locs[i]});
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(d_ids);
-  hipFree(d_y);
-  hipFree(d_out);
-  if (e != hipSuccess) return fail(c, TSAMD_EHIP, "heldout_loglik: %s", hipGetErrorString(e));
+  std::vector<double> sums(req.size(), 0.0);
+  if (!req.empty()) {
+    if (req.size() > c->hreq_cap) {
+      hipFree(c->d_hreq);
+      hipFree(c->d_hsums);
+      c->d_hreq = nullptr, c->d_hsums = nullptr, c->hreq_cap = 0;
+      size_t cap = 64;
+      while (cap < req.size()) cap *= 2;
+      HIP_TRY(c, hipMalloc((void **)&c->d_hreq, cap * sizeof(HeldReq)));
+      HIP_TRY(c, hipMalloc((void **)&c->d_hsums, cap * sizeof(double)));
+      c->hreq_cap = cap;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_hreq, req.data(), req.size() * sizeof(HeldReq), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(ts_heldout_eval, dim3((uint32_t)req.size()), dim3(256), 0, c->stream, c->p.gam, c->npad, c->cfg.k,
+                       c->p.lam, c->d_hids, c->d_hy, c->d_hreq, c->d_hterms, c->d_hsums);
+    HIP_TRY(c, hipMemcpyAsync(sums.data(), c->d_hsums, req.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   double s = 0.0;
-  for (size_t i = 0; i < m; ++i) s += terms[i];  // ascending individual order, like the reference loop
+  uint32_t cnt = 0;
+  for (uint32_t i = 0; i < n; ++i) {  // listed order, like compute_likelihood's loop over the map
+    const bool has = req_of[i] != 0xffffffffu;
+    const double u = has ? sums[req_of[i]] : 0.0;
+    const uint32_t m = has ? req[req_of[i]].len : 0u;
+    if (loc_sums) loc_sums[i] = u;
+    if (loc_counts) loc_counts[i] = m;
+    s += u;
+    cnt += m;
+  }
   if (sum) *sum = s;
-  if (count) *count = (uint32_t)m;
+  if (count) *count = cnt;
   return TSAMD_OK;
+}
+
+int tsamd_heldout_loglik(tsamd_ctx *c, uint32_t loc, double *sum, uint32_t *count) {
+  return tsamd_heldout_eval(c, &loc, 1, 0, nullptr, nullptr, sum, count);
 }
 
 int tsamd_comm_unique_id(uint8_t id[TSAMD_COMM_ID_BYTES]) {
@@ -946,6 +1084,7 @@ int tsamd_comm_init(tsamd_ctx *c, const uint8_t id[TSAMD_COMM_ID_BYTES]) {
   }
   c->split = true;
   c->p.rows_from_lt = 1u;
+  c->rccl_graph = env_u32("TSAMD_RCCL_GRAPH", 0) != 0u;
   destroy_graph(c);
   return TSAMD_OK;
 }
@@ -1078,6 +1217,7 @@ int tsamd_synth_genotypes(tsamd_ctx *c, const double *theta, const double *beta,
   if (rc == TSAMD_OK)
     for (auto it = c->held.lower_bound(first_loc); it != c->held.end() && it->first < first_loc + n_locs;)
       it = c->held.erase(it);
+  c->held_dirty = true;
   return rc;
 }
 
@@ -1088,6 +1228,10 @@ int tsamd_profile_enable(tsamd_ctx *c, int on) {
   c->prof_pass_n = c->prof_first_n = 0;
   c->prof_pass_ms = c->prof_first_ms = 0;
   c->n_ev_pass = c->n_ev_first = 0;
+  c->prof_capped = false;
+  unsigned long long v = 0;
+  HIP_TRY(c, hipMemcpy(&v, &c->p.ctl->total_passes, sizeof v, hipMemcpyDeviceToHost));
+  c->prof_passes0 = v;
   return TSAMD_OK;
 }
 
@@ -1095,10 +1239,56 @@ int tsamd_profile_read(tsamd_ctx *c, uint64_t *pass_launches, double *pass_ms_to
                        double *first_ms_total) {
   CHECK_CTX(c);
   if (int rc = tsamd_synchronize(c)) return rc;
+  // plain passes that really swept: the passes the device counted since profiling was enabled
+  // minus the first passes (a SNP that converges early leaves near-empty launches inside its
+  // bracket; dividing by them would overstate the rate)
+  if (!c->prof_capped && c->prof_first_n) {
+    unsigned long long v = 0;
+    HIP_TRY(c, hipMemcpy(&v, &c->p.ctl->total_passes, sizeof v, hipMemcpyDeviceToHost));
+    const uint64_t ran = v - c->prof_passes0;
+    if (ran >= c->prof_first_n && ran - c->prof_first_n <= c->prof_pass_n) c->prof_pass_n = ran - c->prof_first_n;
+  }
   if (pass_launches) *pass_launches = c->prof_pass_n;
   if (pass_ms_total) *pass_ms_total = c->prof_pass_ms;
   if (first_launches) *first_launches = c->prof_first_n;
   if (first_ms_total) *first_ms_total = c->prof_first_ms;
+  return TSAMD_OK;
+}
+
+int tsamd_probe_stream(tsamd_ctx *c, uint32_t reps, double *read_us, double *rmw_us) {
+  CHECK_CTX(c);
+  if (reps == 0) return fail(c, TSAMD_EINVAL, "reps must be positive");
+  if (int rc = tsamd_synchronize(c)) return rc;
+  HIP_TRY(c, hipSetDevice(c->dev));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(c, hipEventCreate(&e0));
+  HIP_TRY(c, hipEventCreate(&e1));
+  double *sink = c->p.partials;  // never written: the probe's condition cannot hold
+  const uint32_t K = c->cfg.k;
+  const uint32_t chunk_first = (!c->wide && c->first_vec == 2) ? c->p.chunk_first * 2u : c->p.chunk_first;  // individuals
+  const uint32_t chunk_pairs = c->wide ? (c->p.chunk + 1u) / 2u : c->p.chunk;
+  auto timed = [&](bool rmw, double *out_us) -> hipError_t {
+    for (uint32_t r = 0; r < 3u + reps; ++r) {
+      if (r == 3u) (void)hipEventRecord(e0, c->stream);
+      if (rmw)
+        hipLaunchKernelGGL(ts_probe_rmw, dim3(c->grid_first), dim3(256), 0, c->stream, c->p.w, c->p.gam, K, c->npad,
+                           chunk_first, 1.0);
+      else
+        hipLaunchKernelGGL(ts_probe_read, dim3(c->grid), dim3(c->block), 0, c->stream, c->p.w, K, c->npad, chunk_pairs,
+                           c->p.sweep_alternate ? (r & 1u) : 0u, sink);
+    }
+    hipError_t e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (out_us) *out_us = (double)ms * 1e3 / reps;
+    return e;
+  };
+  hipError_t e = timed(false, read_us);
+  if (e == hipSuccess) e = timed(true, rmw_us);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (e != hipSuccess) return fail(c, TSAMD_EHIP, "probe_stream: %s", hipGetErrorString(e));
   return TSAMD_OK;
 }
 

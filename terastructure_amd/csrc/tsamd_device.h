@@ -40,6 +40,8 @@ struct State {
 };
 
 struct Ctl {
+  const uint32_t *sched; // the current schedule (entries: loc | hol_mode << 31), set by ts_begin: not a kernel
+                         // argument of the pass kernels, so captured graphs survive a reallocation
   uint32_t sched_len;   // entries in the schedule; kernels past the end only carry state forward
   uint32_t last_iters;  // inner passes of the most recently completed SNP (for tsamd_snp_update)
   unsigned long long total_passes;
@@ -62,6 +64,13 @@ constexpr int kXchgBlocks = 256;
 struct Xchg {
   double rows[2][kMaxRanks * kXchgBlocks * 2 * TSAMD_MAX_K];
   unsigned long long seq[2][kMaxRanks * kXchgBlocks];
+  // prog[r] = epoch of the launch rank r has STARTED (stored by its workgroup 0 at the start of
+  // every launch of the sequence, into every rank's buffer): rank r has then completed every
+  // earlier launch, reads of the exchange slots included.  A launch that stores rows without
+  // having waited for its peers' rows of the previous launch (a first pass that follows an
+  // early-converged SNP, or starts a schedule) waits for prog >= its own epoch before it
+  // overwrites a slot: two slots are then always enough.
+  unsigned long long prog[kMaxRanks];
   unsigned long long error;  // a bounded wait gave up
 };
 
@@ -75,7 +84,6 @@ struct DevParams {
   double *eb;          // [l][K][2]  exp(Elogbeta)
   Ctl *ctl;
   double *partials;    // [2][kMaxGrid][2K] partial rows, slot = launch parity
-  const uint32_t *sched; // entries: loc | hol_mode << 31
   uint32_t npad;       // padded individuals (multiple of 512)
   uint32_t npairs;     // npad / 2
   uint32_t chunk;      // items (pairs of individuals) per workgroup of the plain pass kernel
@@ -88,6 +96,8 @@ struct DevParams {
   uint32_t xchg_rank;
   Xchg *xchg;            // this rank's buffer
   Xchg *peers[kMaxRanks]; // every rank's buffer as mapped into this process (peers[xchg_rank] == xchg)
+  uint32_t xchg_test_delay;  // test hook (TSAMD_TEST_XCHG_DELAY_US): stall between flag wait and row reads, 10 ns ticks
+  uint32_t xchg_test_noguard; // test hook (TSAMD_TEST_XCHG_NOGUARD): skip the slot-reuse guard (to show the test sees the hazard)
   double alpha, eta0, eta1, nodetau0, nodekappa, gamma_scale, thresh;
 };
 

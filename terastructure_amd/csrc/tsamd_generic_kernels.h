@@ -56,12 +56,10 @@ __global__ void ts_heldout_fold(uint8_t *col, const uint32_t *local_ids, uint32_
   orig[i] = (uint8_t)((old >> sh) & 3u);
 }
 
-// per-entry held-out log-likelihood term (snp_likelihood, src/snpsamplinge.hh:336-360)
-__global__ void ts_heldout_ll(const double *gam, uint32_t npad, uint32_t K, const double *lam_loc,
-                              const uint32_t *local_ids, const uint8_t *ytrue, uint32_t count, double *out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const uint32_t n = local_ids[i];
+// held-out log-likelihood term of one (individual, location) entry (snp_likelihood,
+// src/snpsamplinge.hh:336-360): log(max(C(2,y) q^y (1-q)^(2-y), 1e-30)), q = sum_k Ebeta_k Etheta_nk
+__device__ __forceinline__ double heldout_term(const double *gam, uint32_t npad, uint32_t K, const double *lam_loc,
+                                               uint32_t n, int x) {
   double s = 0.0;
   for (uint32_t k = 0; k < K; ++k) s += gam[(size_t)k * npad + n];
   double q = 0.0;
@@ -72,11 +70,88 @@ __global__ void ts_heldout_ll(const double *gam, uint32_t npad, uint32_t K, cons
     ls += l1;
     q += (l0 / ls) * (gam[(size_t)k * npad + n] / s);
   }
-  const int x = ytrue[i];
   const double v = (x == 1) ? 2.0 : 1.0;  // 2!/(x!(2-x)!)
   double sum = v * pow(q, (double)x) * pow(1.0 - q, (double)(2 - x));
   if (sum < 1e-30) sum = 1e-30;
-  out[i] = log(sum);
+  return log(sum);
+}
+
+// The validation block of compute_likelihood (src/snpsamplinge.cc:476-498) for many locations in
+// one launch: workgroup j handles requested location j -- its held-out entries are a span of the
+// context's flat (ids, true genotypes) table; the terms are computed in parallel and then added
+// by one thread in ascending individual order, the order of the reference's loop (and of
+// the host-side sum this replaces), so the per-location sums are reproducible bit for bit.
+struct HeldReq {
+  unsigned long long start;  // first entry of the location in the flat table
+  uint32_t len, loc;
+};
+__global__ __launch_bounds__(256) void ts_heldout_eval(const double *gam, uint32_t npad, uint32_t K, const double *lam,
+                                                       const uint32_t *ids, const uint8_t *ytrue, const HeldReq *req,
+                                                       double *terms, double *sums) {
+  const HeldReq r = req[blockIdx.x];
+  const double *lam_loc = lam + (size_t)r.loc * 2 * K;
+  for (uint32_t e = threadIdx.x; e < r.len; e += 256u)
+    terms[r.start + e] = heldout_term(gam, npad, K, lam_loc, ids[r.start + e], (int)ytrue[r.start + e]);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    uint32_t e = 0;
+    for (; e + 8u <= r.len; e += 8u) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = terms[r.start + e + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; e < r.len; ++e) s += terms[r.start + e];
+    sums[blockIdx.x] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// On-box ceilings (tsamd_probe_stream): the memory traffic of the two pass kernels with
+// nothing else in them, on the context's own arrays and launch geometry.
+//  ts_probe_read: K row streams of 16-byte loads over a workgroup's chunk of pairs, forwards or
+//                 backwards (the plain pass' weight reads).
+//  ts_probe_rmw:  read w and gamma, write both back unchanged (the first pass' traffic).
+__global__ __launch_bounds__(1024) void ts_probe_read(const double *w, uint32_t K, uint32_t npad, uint32_t chunk,
+                                                      uint32_t rev, double *sink) {
+  const uint32_t npairs = npad / 2;
+  const uint32_t begin = blockIdx.x * chunk, end = min(begin + chunk, npairs);
+  const uint32_t i0 = begin + threadIdx.x;
+  const uint32_t cnt = (i0 < end) ? (end - i0 + blockDim.x - 1u) / blockDim.x : 0u;
+  double acc = 0.0;
+  for (uint32_t t = 0; t < cnt; ++t) {
+    const uint32_t i = rev ? i0 + (cnt - 1u - t) * blockDim.x : i0 + t * blockDim.x;
+#pragma unroll 8
+    for (uint32_t k = 0; k < K; ++k) {
+      const double2 v = reinterpret_cast<const double2 *>(w + (size_t)k * npad)[i];
+      acc += v.x + v.y;
+    }
+  }
+  if (acc == 123.456) sink[0] = acc;  // (keeps the loads alive)
+}
+
+__global__ __launch_bounds__(256) void ts_probe_rmw(double *w, double *gam, uint32_t K, uint32_t npad, uint32_t chunk,
+                                                    double one) {
+  const uint32_t begin = blockIdx.x * chunk, end = min(begin + chunk, npad);
+  for (uint32_t i = begin + threadIdx.x; i < end; i += 256u) {
+    for (uint32_t k0 = 0; k0 < K; k0 += 8u) {
+      double a[8], b[8];
+#pragma unroll
+      for (uint32_t q = 0; q < 8u; ++q) {
+        const uint32_t k = min(k0 + q, K - 1u);
+        a[q] = w[(size_t)k * npad + i];
+        b[q] = gam[(size_t)k * npad + i];
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < 8u; ++q)
+        if (k0 + q < K) {
+          gam[(size_t)(k0 + q) * npad + i] = b[q] * one;  // one == 1.0: the state is unchanged, bit for bit
+          w[(size_t)(k0 + q) * npad + i] = a[q] * one;
+        }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -203,6 +203,65 @@ __device__ __forceinline__ void wait_peer_rows(const DevParams &p, uint32_t slot
   __syncthreads();
 }
 
+// Sharded over the peer-to-peer exchange: workgroup 0 of EVERY launch of the sequence tells every
+// rank that this rank has started launch `epoch_now` (tsamd_device.h, Xchg::prog).
+__device__ __forceinline__ void publish_progress(const DevParams &p, unsigned long long epoch_now) {
+  if (blockIdx.x == 0 && threadIdx.x < p.xchg_world)
+    __hip_atomic_store(&p.peers[threadIdx.x]->prog[p.xchg_rank], epoch_now, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ... and a launch about to store rows WITHOUT having waited for its peers' rows of the previous
+// launch waits (bounded) until every peer has started the same launch: only then has every
+// workgroup of every peer finished reading the slot that is about to be overwritten.  Threads
+// 0 .. world-1 poll one flag each (local, uncached); the caller synchronises the workgroup.
+__device__ __forceinline__ void wait_peer_progress(const DevParams &p, unsigned long long epoch_now) {
+  if (threadIdx.x >= p.xchg_world || p.xchg_test_noguard != 0u) return;
+  if (__hip_atomic_load(&p.xchg->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull) return;
+  const unsigned long long start = wall_clock64();
+  while (__hip_atomic_load(&p.xchg->prog[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch_now) {
+    __builtin_amdgcn_s_sleep(4);
+    if (wall_clock64() - start > 300000000ull) {  // 3 s
+      __hip_atomic_store(&p.xchg->error, epoch_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+}
+
+// test hook: stall a rank between its flag wait and its row reads (tests/test_gpu_multirank.py)
+__device__ __forceinline__ void xchg_test_stall(const DevParams &p) {
+  if (p.xchg_test_delay == 0u) return;
+  const unsigned long long start = wall_clock64();
+  while (wall_clock64() - start < (unsigned long long)p.xchg_test_delay) __builtin_amdgcn_s_sleep(8);
+}
+
+// End of a pass: the workgroup's partial row (value j = tid < J) leaves for the next launch --
+// into this GPU's partial-row slot, or straight into every rank's exchange buffer followed by
+// the epoch flag.  unguarded: the launch did not wait for its peers' previous rows (see above).
+__device__ __forceinline__ void store_row(const DevParams &p, uint32_t par, unsigned long long epoch_now, double v,
+                                          uint32_t J, double *rowsW, bool unguarded) {
+  const uint32_t tid = threadIdx.x;
+  if (p.xchg_world == 0u) {
+    if (tid < J) rowsW[(size_t)blockIdx.x * J + tid] = v;  // read by the NEXT launch only
+    return;
+  }
+  if (unguarded) {
+    wait_peer_progress(p, epoch_now);
+    __syncthreads();
+  }
+  if (tid < J) {
+    // straight into every rank's exchange buffer (one 8-byte store per value and peer)
+    const size_t at = ((size_t)p.xchg_rank * gridDim.x + blockIdx.x) * J + tid;
+    for (uint32_t q = 0; q < p.xchg_world; ++q)
+      __hip_atomic_store(&p.peers[q]->rows[par][at], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+  }
+  __syncthreads();
+  if (tid < p.xchg_world)
+    __hip_atomic_store(&p.peers[tid]->seq[par][p.xchg_rank * gridDim.x + blockIdx.x], epoch_now, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Partial row sum over the exchange buffer: the same fixed order as RowSum (thread (r, j) adds
 // rows r, r+R, ...) with up to 32 loads in flight per thread -- the buffer is uncached, so
 // every batch is a full trip to memory.
@@ -293,7 +352,11 @@ struct Lanes<2> {
 #define TSAMD_FIRST_WAVES 1
 #endif
 template <int KT, bool FIRST, int BLOCK, int VEC>
-__global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1) void ts_pass(DevParams p, uint32_t par, uint32_t nrows_hint) {
+__global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1) void ts_pass(DevParams p, uint32_t par_arg, uint32_t nrows_hint) {
+  // par_arg: bit 0 = launch parity (state / partial-row slot written), bit 1 = plain pass sweeps
+  // its chunk backwards (set for the odd passes of a SNP, a property of the pass, not of the
+  // launch parity: any cut of a schedule into calls or graphs gives the same summation order)
+  const uint32_t par = par_arg & 1u;
   constexpr int kWaves = BLOCK / 64;
   using LN = Lanes<VEC>;
   using WT = typename LN::T;
@@ -338,13 +401,13 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const bool local_rows = p.xchg_world == 0u && p.rows_from_lt == 0u;
   RowSum<BLOCK> rowsum;
   rowsum.issue(p.partials + (size_t)(par ^ 1u) * kMaxGrid * (2 * KT), local_rows ? nrows_hint : 0u, 2 * KT);
-  // Plain passes sweep their chunk forwards and backwards alternately (the launch parity
-  // alternates): a pass starts on the addresses the previous one touched last (measured
+  // Plain passes sweep their chunk forwards and backwards alternately (passes 2, 4, ... of a
+  // SNP backwards): a pass starts on the addresses the previous one touched last (measured
   // 13.1 -> 11.1 us at N = 1M, K = 8; TSAMD_SWEEP=0 disables).
   WT bufA[KT];
   const uint32_t i0 = begin + tid;
   const uint32_t cnt = (i0 < end) ? (end - i0 + BLOCK - 1u) / BLOCK : 0u;  // this thread's items
-  const bool rev = !FIRST && (par & 1u) != 0u && p.sweep_alternate != 0u;
+  const bool rev = !FIRST && (par_arg & 2u) != 0u && p.sweep_alternate != 0u;
   auto item = [&](uint32_t t) { return rev ? i0 + (cnt - 1u - t) * BLOCK : i0 + t * BLOCK; };
   if (!FIRST && cnt) load_rows(item(0), bufA);
   __builtin_amdgcn_sched_barrier(0);
@@ -352,6 +415,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
   const uint32_t siters = S->iters, snrows = S->nrows;
   const uint32_t sched_len = ctl->sched_len;
+  const uint32_t *sched = ctl->sched;
   const PendingIn pin = load_pending(S, J);
   // plain pass: the location is known as soon as the state is (it only changes in a first
   // pass), so the first column word is requested now and arrives during the epilogue
@@ -370,7 +434,14 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
 #endif
   TSAMD_TR(1);
   const bool pending = svalid != 0u && sdone == 0u;
-  if (pending && p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
+  const unsigned long long epoch_now = S->epoch + 1ull;
+  if (p.xchg_world) {
+    publish_progress(p, epoch_now);
+    if (pending) {
+      wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
+      xchg_test_stall(p);
+    }
+  }
   double vrow = 0.0;
   if (pending)
     vrow = (local_rows && nrowsR == nrows_hint) ? rowsum.finish()
@@ -407,7 +478,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
       }
       return;
     }
-    const uint32_t ent = p.sched[idx];
+    const uint32_t ent = sched[idx];
     loc = ent & 0x7fffffffu;
     hol = ent >> 31;
     iters = 1u;
@@ -612,25 +683,14 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     if ((lane & (kRep - 1u)) == 0u && slot < (int)J) s_red[wave][slot] = tot;
   }
   __syncthreads();
-  if (tid < J) {
-    double v = s_red[0][tid];
+  {
+    double v = 0.0;
+    if (tid < J) {
+      v = s_red[0][tid];
 #pragma unroll
-    for (int wv = 1; wv < kWaves; ++wv) v += s_red[wv][tid];
-    if (p.xchg_world == 0u) {
-      rowsW[(size_t)blockIdx.x * J + tid] = v;  // read by the NEXT launch only
-    } else {
-      // straight into every rank's exchange buffer (one 8-byte store per value and peer)
-      const size_t at = ((size_t)p.xchg_rank * gridDim.x + blockIdx.x) * J + tid;
-      for (uint32_t q = 0; q < p.xchg_world; ++q)
-        __hip_atomic_store(&p.peers[q]->rows[par][at], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __threadfence_system();
+      for (int wv = 1; wv < kWaves; ++wv) v += s_red[wv][tid];
     }
-  }
-  if (p.xchg_world) {
-    __syncthreads();
-    if (tid < p.xchg_world)
-      __hip_atomic_store(&p.peers[tid]->seq[par][p.xchg_rank * gridDim.x + blockIdx.x], S->epoch + 1ull,
-                         __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    store_row(p, par, epoch_now, v, J, rowsW, FIRST && !pending);
   }
 
   // workgroup 0 publishes the state the next launch starts from
@@ -648,7 +708,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
       W->iters = iters;
       W->done = 0u;
       W->nrows = gridDim.x;
-      W->epoch = S->epoch + 1ull;
+      W->epoch = epoch_now;
     }
   }
 #ifdef TSAMD_TRACE
@@ -676,9 +736,13 @@ __global__ __launch_bounds__(BLOCK) void ts_flush(DevParams p, uint32_t par) {
   State *W = &ctl->st[par];
   const uint32_t J = 2 * p.K;
   const PendingIn pin = load_pending(S, J);
+  if (p.xchg_world) publish_progress(p, S->epoch + 1ull);
   if (S->valid != 0u && S->done == 0u) {
     const uint32_t nrowsR = p.xchg_world ? p.xchg_world * S->nrows : p.rows_from_lt ? 1u : S->nrows;
-    if (p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
+    if (p.xchg_world) {
+      wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
+      xchg_test_stall(p);
+    }
     const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                           : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
                                            : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
@@ -692,13 +756,17 @@ __global__ __launch_bounds__(BLOCK) void ts_flush(DevParams p, uint32_t par) {
 
 // Start of a schedule of n entries.  drop_pending: forget the pending gamma step
 // (tsamd_clear_pending).  n == 0xffffffff keeps the current schedule length.
-__global__ void ts_begin(Ctl *ctl, uint32_t n, uint32_t par, uint32_t J, uint32_t drop_pending) {
+__global__ void ts_begin(DevParams p, const uint32_t *sched, uint32_t n, uint32_t par, uint32_t drop_pending) {
+  Ctl *ctl = p.ctl;
+  const uint32_t J = 2 * p.K;
   const State *S = &ctl->st[par ^ 1u];
   State *W = &ctl->st[par];
+  if (p.xchg_world) publish_progress(p, S->epoch + 1ull);
   carry_state(S, W, J);
   __syncthreads();
   if (threadIdx.x == 0) {
     if (n != 0xffffffffu) {
+      ctl->sched = sched;
       ctl->sched_len = n;
       W->idx = 0xffffffffu;
     }

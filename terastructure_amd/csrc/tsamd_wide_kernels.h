@@ -16,7 +16,8 @@ constexpr int kWideChunk = 8;   // populations accumulated per register chunk
 constexpr int kWideJ = 2 * TSAMD_MAX_K;
 
 template <bool FIRST>
-__global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t par, uint32_t nrows_hint) {
+__global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t par_arg, uint32_t nrows_hint) {
+  const uint32_t par = par_arg & 1u;  // (bit 1, the sweep direction of ts_pass, does not apply here)
   constexpr int BLOCK = kWideBlock;
   constexpr int kWaves = BLOCK / 64;
   __shared__ double s_eb[kWideJ];
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t
   const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
   const uint32_t siters = S->iters, snrows = S->nrows;
   const uint32_t sched_len = ctl->sched_len;
+  const uint32_t *sched = ctl->sched;
   const PendingIn pin = load_pending(S, J);
   const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                         : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
@@ -50,7 +52,14 @@ __global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t
   double *rowsW = p.partials + (size_t)par * kMaxGrid * J;
 
   const bool pending = svalid != 0u && sdone == 0u;
-  if (pending && p.xchg_world) wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
+  const unsigned long long epoch_now = S->epoch + 1ull;
+  if (p.xchg_world) {
+    publish_progress(p, epoch_now);
+    if (pending) {
+      wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
+      xchg_test_stall(p);
+    }
+  }
   double vrow = 0.0;
   if (pending) vrow = row_partial_sum<BLOCK>(rowsR, nrowsR, J);
   uint32_t loc, hol, idx, iters;
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t
       }
       return;
     }
-    const uint32_t ent = p.sched[idx];
+    const uint32_t ent = sched[idx];
     loc = ent & 0x7fffffffu;
     hol = ent >> 31;
     iters = 1u;
@@ -199,23 +208,13 @@ __global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t
     if ((lane & (kRep - 1u)) == 0u && 2 * k0 + (uint32_t)slot < J) s_red[wave][2 * k0 + slot] = tot;
   }
   __syncthreads();
-  if (tid < J) {
-    double v = s_red[0][tid];
-    for (int wv = 1; wv < kWaves; ++wv) v += s_red[wv][tid];
-    if (p.xchg_world == 0u) {
-      rowsW[(size_t)blockIdx.x * J + tid] = v;
-    } else {
-      const size_t at = ((size_t)p.xchg_rank * gridDim.x + blockIdx.x) * J + tid;
-      for (uint32_t q = 0; q < p.xchg_world; ++q)
-        __hip_atomic_store(&p.peers[q]->rows[par][at], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __threadfence_system();
+  {
+    double v = 0.0;
+    if (tid < J) {
+      v = s_red[0][tid];
+      for (int wv = 1; wv < kWaves; ++wv) v += s_red[wv][tid];
     }
-  }
-  if (p.xchg_world) {
-    __syncthreads();
-    if (tid < p.xchg_world)
-      __hip_atomic_store(&p.peers[tid]->seq[par][p.xchg_rank * gridDim.x + blockIdx.x], S->epoch + 1ull,
-                         __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    store_row(p, par, epoch_now, v, J, rowsW, FIRST && !pending);
   }
 
   if (blockIdx.x == 0) {
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(kWideBlock) void ts_pass_wide(DevParams p, uint32_t
       W->iters = iters;
       W->done = 0u;
       W->nrows = gridDim.x;
-      W->epoch = S->epoch + 1ull;
+      W->epoch = epoch_now;
     }
   }
 }

@@ -162,6 +162,10 @@ class Engine:
     def synchronize(self):
         self._check(self.h.tsamd_synchronize(self.ctx))
 
+    def prepare(self):
+        """capture + instantiate the replayed hipGraphs now (otherwise the first run_schedule does)"""
+        self._check(self.h.tsamd_prepare(self.ctx))
+
     def total_passes(self):
         v = C.c_uint64(0)
         self._check(self.h.tsamd_total_passes(self.ctx, C.byref(v)))
@@ -180,6 +184,17 @@ class Engine:
         s, c = C.c_double(0), C.c_uint32(0)
         self._check(self.h.tsamd_heldout_loglik(self.ctx, loc, C.byref(s), C.byref(c)))
         return s.value, c.value
+
+    def heldout_eval(self, locs, run_updates=True):
+        """(sum, count, per-location sums, per-location counts) of the held-out log-likelihood over
+        locs -- tsamd_heldout_eval: the validation block of compute_likelihood in one call."""
+        a = np.ascontiguousarray(locs, dtype=np.uint32)
+        sums = np.zeros(a.size, dtype=np.float64)
+        cnts = np.zeros(a.size, dtype=np.uint32)
+        s, c = C.c_double(0), C.c_uint32(0)
+        self._check(self.h.tsamd_heldout_eval(self.ctx, _up(a), a.size, int(run_updates), _dp(sums), _up(cnts),
+                                              C.byref(s), C.byref(c)))
+        return s.value, c.value, sums, cnts
 
     # -- multi-GPU --------------------------------------------------------------
     def comm_unique_id(self):
@@ -231,6 +246,12 @@ class Engine:
         pm, fm = C.c_double(0), C.c_double(0)
         self._check(self.h.tsamd_profile_read(self.ctx, C.byref(pn), C.byref(pm), C.byref(fn), C.byref(fm)))
         return dict(pass_launches=pn.value, pass_ms=pm.value, first_launches=fn.value, first_ms=fm.value)
+
+    def probe_stream(self, reps=50):
+        """(read_us, rmw_us): bare streaming read of w / read-modify-write of w and gamma per launch"""
+        a, b = C.c_double(0), C.c_double(0)
+        self._check(self.h.tsamd_probe_stream(self.ctx, reps, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def mem_info(self):
         f, t = C.c_uint64(0), C.c_uint64(0)

@@ -1,4 +1,6 @@
 """Shared builders for parity tests: seeded PSD genotypes as PLINK payloads."""
+import os
+
 import numpy as np
 
 # PLINK 2-bit code of genotype y (count of A2): 0 -> 00, 1 -> 10, 2 -> 11, missing -> 01
@@ -43,3 +45,22 @@ def init_gamma(n, k, seed):
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-300)))
+
+
+def usable_cores():
+    """Host cores this process may really use: the smaller of the affinity mask and the
+    cgroup CPU quota (a container can see 256 CPUs and be entitled to 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n

@@ -23,7 +23,12 @@ def main():
     y, _, _ = psd_genotypes(n, l, k, seed, 0.03)
     payload = pack_bed(y)
     gamma = init_gamma(n, k, seed + 1)
-    eng = ts.Engine(n, l, k, device=device, rank=rank, world=world)
+    over = {}
+    if os.environ.get("TS_CONV_THRESH"):      # early convergence: SNPs stop after differing pass counts
+        over["conv_thresh"] = float(os.environ["TS_CONV_THRESH"])
+    if os.environ.get("TS_DELAY_RANK") == str(rank):  # this rank stalls between its flag wait and its row reads
+        os.environ["TSAMD_TEST_XCHG_DELAY_US"] = os.environ.get("TS_DELAY_US", "200")
+    eng = ts.Engine(n, l, k, device=device, rank=rank, world=world, flags=int(os.environ.get("TS_FLAGS", "0")), **over)
     b, c = eng.shard_begin, eng.shard_count
     eng.upload_bed(payload)
     eng.set_gamma(gamma[b:b + c])
@@ -34,7 +39,17 @@ def main():
     if mode == "p2p":
         tdist.bootstrap_p2p(eng, d)
     else:
-        tdist.bootstrap_comm(eng, d)
+        err = None
+        try:
+            tdist.bootstrap_comm(eng, d)
+        except Exception as exc:  # noqa: BLE001 -- e.g. RCCL refuses two ranks on one device
+            err = exc
+        if not tdist.all_ok(err is None, d):
+            print(f"RCCL communicator unavailable: {err}", flush=True)
+            d.barrier()
+            eng.close()
+            d.destroy_process_group()
+            sys.exit(77)
     locs = np.random.default_rng(seed + 3).integers(0, l, size=nsnp).astype(np.uint32)
     eng.run_schedule(locs[:5])          # eager path
     eng.synchronize()

@@ -31,6 +31,28 @@ def test_bench_json_contract():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    assert "N=30000 K=8" in d["metric"]                                       # names the workload that ran
+    assert rf["probe_read_us"] > 0 and "Infinity Cache" in rf["ceiling_note"]
+    fp = rf["first_pass"]
+    assert fp["bound"] == "hbm" and abs(fp["frac"] - fp["achieved"] / fp["peak"]) < 1e-3 and fp["probe_rmw_us"] > 0
+    assert fp["algorithmic_bytes_per_launch"] == 32.0 * 30000 * 8 + 8.0 * 30000 + 30000 / 2.0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] and cb["sample"]
+    assert cb["value_1_thread"] > 0
+    pv = d["parity_vs_cpu_baseline"]                                         # GPU vs the oracle on the timed updates
+    assert pv["ok"] and pv["c_n_equal"] and pv["lambda_rel_err"] < 1e-9 and pv["gamma_rel_err"] < 1e-9
     assert sum(d["inner_passes_histogram"].values()) == 60
+
+
+def test_bench_short_run_matches_long_run():
+    """The driver times `--steps 20 --warmup 5`: graphs are built before the timed region and a
+    schedule of any length replays without padding, so the short run's per-update time is the long
+    run's (small workload here, where fixed costs weigh most: within 25 %)."""
+    vals = {}
+    for steps, warm in ((20, 5), (600, 50)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps),
+                            "--warmup", str(warm), "--individuals", "200000", "--snps", "300", "--pops", "8",
+                            "--cpu-seconds", "0", "--no-profile"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        vals[steps] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["value"]
+    assert vals[20] > 0.75 * vals[600], vals

@@ -297,14 +297,18 @@ def test_config1_reference_fixture(ts):
         eng.run_schedule(locs)
         for loc in locs:
             orc.snp_update(int(loc))
-        sd = so = 0.0
-        cnt = 0
-        for loc in orc.heldout_locs():
-            assert eng.snp_update(int(loc), 1) == orc.snp_update(int(loc), 1)
-            a, c = eng.heldout_loglik(int(loc))
+        # the validation block in one call (tsamd_heldout_eval): hol-mode schedule over the
+        # validation locations + one evaluation kernel; the oracle goes location by location
+        vlocs = orc.heldout_locs()
+        p0 = eng.total_passes()
+        sd, cnt, sums_d, cnts_d = eng.heldout_eval(vlocs)
+        so, its_o = 0.0, 0
+        for j, loc in enumerate(vlocs):
+            its_o += orc.snp_update(int(loc), 1)
             b, c2 = orc.heldout_loglik(int(loc))
-            assert c == c2
-            sd, so, cnt = sd + a, so + b, cnt + c
+            assert cnts_d[j] == c2 and abs(sums_d[j] - b) <= 1e-9 * abs(b)
+            so += b
+        assert eng.total_passes() - p0 == its_o
         assert cnt == 1000
         assert "%.9f" % (so / cnt) == "-0.732008912"  # validation.txt line 2 of the reference run
         assert abs(sd / cnt - so / cnt) < 1e-9
@@ -381,3 +385,38 @@ def test_wide_k_graph_replay_bitwise(ts):
                 b, c2 = orc.heldout_loglik(hl)
                 assert c == c2 and abs(a - b) <= 1e-10 * abs(b)
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_heldout_eval_equals_per_location_path_bitwise(ts):
+    """tsamd_heldout_eval (one schedule + one kernel) == snp_update(loc, hol) + heldout_loglik per
+    location, bit for bit, including locations without held-out entries and the
+    evaluate-only mode used for the initial likelihood."""
+    n, l, k = 5000, 40, 6
+    train = np.random.default_rng(2).integers(0, l, size=25).astype(np.uint32)
+    outs = []
+    for mode in ("block", "per-location"):
+        eng, orc, _ = make_pair(ts, n, l, k, 404)
+        with eng:
+            vl = [int(x) for x in orc.heldout_locs()] + [0 if 0 not in orc.heldout_locs() else 1]
+            vl = np.array(sorted(set(vl)), dtype=np.uint32)
+            s0 = eng.heldout_eval(vl, run_updates=False)            # initial likelihood: no updates
+            assert s0[1] == sum(len(orc.heldout_indivs(int(x))) for x in orc.heldout_locs())
+            eng.run_schedule(train)
+            eng.synchronize()
+            if mode == "block":
+                s, c, sums, cnts = eng.heldout_eval(vl)
+            else:
+                sums, cnts = np.zeros(len(vl)), np.zeros(len(vl), dtype=np.uint32)
+                for j, loc in enumerate(vl):
+                    eng.snp_update(int(loc), 1)
+                    sums[j], cnts[j] = eng.heldout_loglik(int(loc))
+                s, c = 0.0, 0
+                for j in range(len(vl)):
+                    s += sums[j]
+                    c += int(cnts[j])
+            outs.append((s, c, sums.copy(), cnts.copy(), eng.get_lambda(), eng.get_gamma(), s0[0]))
+    a, b = outs
+    assert a[0] == b[0] and a[1] == b[1] and a[6] == b[6]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    assert (a[3] == 0).any() and (a[3] > 0).any()

@@ -1,0 +1,157 @@
+"""GPU parity at the BENCHMARKED launch geometry: the HIP path (through the C ABI) against the
+CPU oracle at sizes where a thread of the plain pass owns several items (two-stage software
+pipeline, backwards sweeps, 512-thread workgroups, several batches of partial rows) and the
+first pass walks several individuals per thread -- BASELINE configs 4 and 5 on one GPU.
+
+The oracle (oracle/ts_oracle.c, the reference's arithmetic: logsum softmax, k-outer/n-inner
+sums) runs with all usable host cores in the reference's work partition
+(src/snpsamplinge.cc:298-318, :337-352); its per-thread partial sums are added in chunk order,
+which moves results by rounding only.
+
+Tolerances: lambda and gamma rel 1e-9 after ~20 updates; inner-pass counts and c_n exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as op
+from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, usable_cores
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ts():
+    import terastructure_amd as t
+
+    t.load()
+    return t
+
+
+def _held_sets(y, seed, per_loc):
+    """{loc: held-out individuals}: two locations, observed genotypes only"""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for loc in (1, 5):
+        cand = np.nonzero(y[loc] != 3)[0]
+        out[loc] = np.sort(rng.choice(cand, size=per_loc, replace=False)).astype(np.uint32)
+    return out
+
+
+# training updates (consecutive repeats included), one validation-mode update of a held-out
+# location, training again: 17 + 1 + 4 updates = graphs of 16 + 1, 1, 4 SNPs
+CALLS = [([3, 3, 5, 1, 6, 1, 2, 0, 7, 7, 4, 5, 3, 6, 2, 1, 0], 0), ([5], 1), ([6, 1, 6, 0], 0)]
+
+
+@pytest.mark.parametrize("n,k,thresh", [(300_000, 8, None), (1_000_000, 8, None), (125_000, 20, None),
+                                        (1_000_000, 20, None), (300_000, 8, 20.0), (1_000_000, 20, 40.0)])
+def test_benchmarked_geometry_matches_oracle(ts, n, k, thresh):
+    """run_schedule (hipGraph replay) and eager snp_update calls at N up to 1M, K = 8 and 20;
+    `thresh` raises meanchangethresh so that SNPs stop after differing numbers of passes."""
+    l = 8
+    y, _, _ = psd_genotypes(n, l, k, 4000 + k, 0.02)
+    payload = pack_bed(y)
+    g = init_gamma(n, k, 4001 + k)
+    held = _held_sets(y, 4002 + k, n // 100)
+    del y
+    over_o = {} if thresh is None else {"meanchangethresh": thresh}
+    over_d = {} if thresh is None else {"conv_thresh": thresh}
+
+    orc = op.Oracle(n, l, k, nthreads=usable_cores(), **over_o)
+    orc.load_bed_payload(payload)
+    orc.set_gamma(g)
+    for loc, ids in held.items():
+        orc.set_heldout(loc, ids)
+    its = [orc.snp_update(loc, hol) for locs, hol in CALLS for loc in locs]
+    lam_o, gam_o, cnt_o = orc.lambda_(), orc.gamma(), orc.c_indiv()
+    orc.close()
+    if thresh is None:
+        assert set(its) == {10}
+    else:
+        assert len(set(its)) >= 3, f"pass counts do not vary: {sorted(set(its))}"
+
+    res = {}
+    for mode in ("graph", "eager"):
+        with ts.Engine(n, l, k, flags=0 if mode == "graph" else ts.FLAG_NO_GRAPH, **over_d) as eng:
+            eng.upload_bed(payload)
+            eng.set_gamma(g)
+            for loc, ids in held.items():
+                eng.set_heldout(loc, ids)
+            if mode == "graph":
+                for locs, hol in CALLS:
+                    eng.run_schedule(np.array(locs, dtype=np.uint32), hol)
+                eng.synchronize()
+            else:
+                its_d = [eng.snp_update(loc, hol) for locs, hol in CALLS for loc in locs]
+                assert its_d == its
+            assert eng.total_passes() == sum(its)
+            assert np.array_equal(eng.pass_histogram(), np.bincount(its, minlength=128).astype(np.uint64))
+            lam_d, gam_d, cnt_d = eng.get_lambda(), eng.get_gamma(), eng.get_counts()
+        assert np.array_equal(cnt_d, cnt_o), mode + " c_n"
+        e_lam, e_gam = rel_err(lam_d, lam_o), rel_err(gam_d, gam_o)
+        assert e_lam < 1e-9 and e_gam < 1e-9, (mode, e_lam, e_gam)
+        res[mode] = (lam_d, gam_d)
+    # and graph replay == eager launches, bit for bit
+    assert np.array_equal(res["graph"][0], res["eager"][0]) and np.array_equal(res["graph"][1], res["eager"][1])
+
+
+@pytest.mark.parametrize("k,block", [(1, 256), (3, 512), (8, 256), (8, 512), (8, 1024), (12, 512), (16, 512), (17, 256),
+                                     (20, 256), (32, 256)])
+def test_multi_item_loops_every_instantiation(ts, k, block, monkeypatch):
+    """Four workgroups for 20 000 individuals (TSAMD_GRID / TSAMD_GRID_FIRST = 4): every thread of
+    the plain pass owns 5-10 items and of the first pass 20, at each workgroup size the library
+    can pick -- the pipelined loop, its clamped prefetch and the backwards sweep of every
+    K-specialised instantiation meet the oracle at a size the oracle finishes in a second."""
+    monkeypatch.setenv("TSAMD_GRID", "4")
+    monkeypatch.setenv("TSAMD_GRID_FIRST", "4")
+    monkeypatch.setenv("TSAMD_BLOCK", str(block))
+    n, l = 20_000, 12
+    y, _, _ = psd_genotypes(n, l, k, 700 + k, 0.03)
+    payload = pack_bed(y)
+    g = init_gamma(n, k, 701 + k)
+    orc = op.Oracle(n, l, k, nthreads=usable_cores())
+    orc.load_bed_payload(payload)
+    orc.set_gamma(g)
+    locs = np.random.default_rng(k).integers(0, l, size=21).astype(np.uint32)
+    locs[3] = locs[2]
+    its = [orc.snp_update(int(loc)) for loc in locs]
+    with ts.Engine(n, l, k) as eng:
+        eng.upload_bed(payload)
+        eng.set_gamma(g)
+        eng.run_schedule(locs)
+        eng.synchronize()
+        assert eng.total_passes() == sum(its)
+        assert np.array_equal(eng.get_counts(), orc.c_indiv())
+        assert rel_err(eng.get_lambda(), orc.lambda_()) < 1e-9
+        assert rel_err(eng.get_gamma(), orc.gamma()) < 1e-9
+
+
+def test_clear_pending_then_schedule_equals_eager_bitwise(ts):
+    """A single extra kernel between schedules (tsamd_clear_pending) shifts the launch parity of
+    everything after it; the sweep direction of a pass follows its index within the SNP, not the
+    launch parity, so graph replay still equals the eager sequence bit for bit (and an odd
+    max_inner, where every SNP shifts the parity, does too)."""
+    n, l, k = 600_000, 16, 8
+    y, _, _ = psd_genotypes(n, l, k, 31, 0.02)
+    payload = pack_bed(y)
+    g = init_gamma(n, k, 32)
+    del y
+    locs_a = np.array([2, 9, 9, 4, 11], dtype=np.uint32)
+    locs_b = np.random.default_rng(3).integers(0, l, size=19).astype(np.uint32)
+    for max_inner in (10, 7):
+        outs = []
+        for flags in (0, ts.FLAG_NO_GRAPH):
+            with ts.Engine(n, l, k, flags=flags, max_inner=max_inner) as eng:
+                eng.upload_bed(payload)
+                eng.set_gamma(g)
+                eng.run_schedule(locs_a)
+                eng.clear_pending()
+                eng.run_schedule(locs_b)
+                eng.clear_pending()
+                eng.clear_pending()
+                eng.run_schedule(locs_a[:3])
+                eng.synchronize()
+                outs.append((eng.get_lambda(), eng.get_gamma(), eng.get_counts(), eng.total_passes()))
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a, b), f"max_inner={max_inner}"
