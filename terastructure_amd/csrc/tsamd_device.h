@@ -39,6 +39,16 @@ struct State {
   double eb[2 * TSAMD_MAX_K];   // exp(Elogbeta[loc]) used by pass `iters` (the last executed pass)
 };
 
+// What the first pass of the NEXT SNP needs besides the state, captured one SNP ahead by workgroup
+// 0 of a first pass (slot = schedule index & 1): the schedule entry and lambda / exp(Elogbeta) of its
+// location.  Valid for schedule index for_idx only; unusable when that location equals the
+// previous SNP's (its values were still being updated when this was captured).
+struct NextSnp {
+  uint32_t for_idx, ent, pad[2];
+  double lam[2 * TSAMD_MAX_K];
+  double eb[2 * TSAMD_MAX_K];
+};
+
 struct Ctl {
   const uint32_t *sched; // the current schedule (entries: loc | hol_mode << 31), set by ts_begin: not a kernel
                          // argument of the pass kernels, so captured graphs survive a reallocation
@@ -49,6 +59,7 @@ struct Ctl {
   State st[2];
   double lt[2][2 * TSAMD_MAX_K];      // sharded: this shard's summed partial rows (all-reduce input)
   double lt_sum[2][2 * TSAMD_MAX_K];  // all-reduced; read as the single "row" of the previous pass
+  NextSnp nxt[2];
 };
 
 // Peer-to-peer exchange buffer of one rank (fine-grained, IPC-shared).  Every workgroup of

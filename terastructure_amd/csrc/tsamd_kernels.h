@@ -400,7 +400,13 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   // launch-time constant -- then the first item's row data.
   const bool local_rows = p.xchg_world == 0u && p.rows_from_lt == 0u;
   RowSum<BLOCK> rowsum;
-  rowsum.issue(p.partials + (size_t)(par ^ 1u) * kMaxGrid * (2 * KT), local_rows ? nrows_hint : 0u, 2 * KT);
+#ifdef TSAMD_FIRST_FAST
+  // (first pass: only workgroup 0 needs the previous SNP's rows unless the slow path is taken)
+  const bool rows_issued = local_rows && (!FIRST || blockIdx.x == 0);
+#else
+  const bool rows_issued = local_rows;
+#endif
+  rowsum.issue(p.partials + (size_t)(par ^ 1u) * kMaxGrid * (2 * KT), rows_issued ? nrows_hint : 0u, 2 * KT);
   // Plain passes sweep their chunk forwards and backwards alternately (passes 2, 4, ... of a
   // SNP backwards): a pass starts on the addresses the previous one touched last (measured
   // 13.1 -> 11.1 us at N = 1M, K = 8; TSAMD_SWEEP=0 disables).
@@ -417,6 +423,21 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t sched_len = ctl->sched_len;
   const uint32_t *sched = ctl->sched;
   const PendingIn pin = load_pending(S, J);
+#ifdef TSAMD_FIRST_FAST
+  // first pass: what it needs about the new SNP was captured one SNP ahead (NextSnp); both slots
+  // are requested with the state, the one whose for_idx matches is used
+  uint32_t nx_for[2] = {0xffffffffu, 0xffffffffu}, nx_ent[2] = {0u, 0u};
+  double nx_lam[2] = {0.0, 0.0}, nx_eb[2] = {0.0, 0.0};
+  if constexpr (FIRST) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      nx_for[q] = ctl->nxt[q].for_idx;
+      nx_ent[q] = ctl->nxt[q].ent;
+      nx_lam[q] = ctl->nxt[q].lam[tid < J ? tid : 0u];
+      nx_eb[q] = ctl->nxt[q].eb[tid < J ? tid : 0u];
+    }
+  }
+#endif
   // plain pass: the location is known as soon as the state is (it only changes in a first
   // pass), so the first column word is requested now and arrives during the epilogue
   uint32_t word_early = 0;
@@ -435,18 +456,37 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   TSAMD_TR(1);
   const bool pending = svalid != 0u && sdone == 0u;
   const unsigned long long epoch_now = S->epoch + 1ull;
+#ifdef TSAMD_FIRST_FAST
+  // First pass, fast path: the new SNP's entry and values come from NextSnp, and the previous
+  // SNP's epilogue (row sum, update_lambda, estimate_beta) is only needed for publishing its final
+  // values -- workgroup 0's job; every other workgroup goes straight to the sweep.  Slow path (the
+  // first SNP of a schedule, the same location twice in a row, the end of the schedule): everybody
+  // runs the epilogue and the values are read from the global arrays, as in a plain pass.
+  int nx_sel = -1;
+  if constexpr (FIRST) {
+    const uint32_t nidx = sidx + 1u;
+    nx_sel = nx_for[0] == nidx ? 0 : nx_for[1] == nidx ? 1 : -1;
+    if (nx_sel >= 0 && (nidx >= sched_len || (nx_ent[nx_sel] & 0x7fffffffu) == sloc)) nx_sel = -1;
+  }
+  const bool first_fast = FIRST && nx_sel >= 0;
+  const bool need_epilogue = pending && (!first_fast || blockIdx.x == 0);
+#else
+  const bool need_epilogue = pending;
+#endif
+  bool synced = false;  // sharded peer-to-peer: this workgroup has waited for its peers' previous rows
   if (p.xchg_world) {
     publish_progress(p, epoch_now);
-    if (pending) {
+    if (need_epilogue) {
       wait_peer_rows(p, par ^ 1u, S->epoch, nrowsR);
       xchg_test_stall(p);
+      synced = true;
     }
   }
   double vrow = 0.0;
-  if (pending)
-    vrow = (local_rows && nrowsR == nrows_hint) ? rowsum.finish()
-           : p.xchg_world                       ? row_partial_sum_xchg<BLOCK>(rowsR, nrowsR, J)
-                                                : row_partial_sum<BLOCK>(rowsR, nrowsR, J);
+  if (need_epilogue)
+    vrow = (rows_issued && nrowsR == nrows_hint) ? rowsum.finish()
+           : p.xchg_world                        ? row_partial_sum_xchg<BLOCK>(rowsR, nrowsR, J)
+                                                 : row_partial_sum<BLOCK>(rowsR, nrowsR, J);
   TSAMD_TR(2);
   uint32_t loc, hol, idx, iters;
   bool do_gamma = false;
@@ -468,7 +508,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     iters = siters + 1u;
   } else {
     idx = sidx + 1u;  // 0xffffffff + 1 = 0: first SNP of the schedule
-    if (pending) finish_pending<BLOCK>(p, pin, vrow, J, s_fin, s_plam, s_peb, s_diff);
+    if (need_epilogue) finish_pending<BLOCK>(p, pin, vrow, J, s_fin, s_plam, s_peb, s_diff);
     if (idx >= sched_len) {  // schedule exhausted: complete what is pending, carry state
       if (blockIdx.x == 0) {
         if (pending)
@@ -478,20 +518,34 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
       }
       return;
     }
-    const uint32_t ent = sched[idx];
-    loc = ent & 0x7fffffffu;
-    hol = ent >> 31;
     iters = 1u;
     do_gamma = svalid != 0u && shol == 0u;
     prev_loc = sloc;
-    if (tid < J) {
-      s_sb[tid] = S->eb[tid];
-      if (pending && sloc == loc) {  // same location twice in a row: its final values are still local
-        s_lam[tid] = s_plam[tid];
-        s_eb[tid] = s_peb[tid];
-      } else {
-        s_lam[tid] = p.lam[(size_t)loc * J + tid];
-        s_eb[tid] = p.eb[(size_t)loc * J + tid];
+#ifdef TSAMD_FIRST_FAST
+    if (first_fast) {
+      const uint32_t ent = nx_sel ? nx_ent[1] : nx_ent[0];
+      loc = ent & 0x7fffffffu;
+      hol = ent >> 31;
+      if (tid < J) {
+        s_sb[tid] = pin.eb_used;  // = S->eb[tid]
+        s_lam[tid] = nx_sel ? nx_lam[1] : nx_lam[0];
+        s_eb[tid] = nx_sel ? nx_eb[1] : nx_eb[0];
+      }
+    } else
+#endif
+    {
+      const uint32_t ent = sched[idx];
+      loc = ent & 0x7fffffffu;
+      hol = ent >> 31;
+      if (tid < J) {
+        s_sb[tid] = S->eb[tid];
+        if (pending && sloc == loc) {  // same location twice in a row: its final values are still local
+          s_lam[tid] = s_plam[tid];
+          s_eb[tid] = s_peb[tid];
+        } else {
+          s_lam[tid] = p.lam[(size_t)loc * J + tid];
+          s_eb[tid] = p.eb[(size_t)loc * J + tid];
+        }
       }
     }
     __syncthreads();
@@ -587,8 +641,15 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     double sb0[KT], sb1[KT];  // exp(Elogbeta) of the previous SNP's last pass (wave-uniform)
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
+#ifdef TSAMD_SB_VGPR
+      // (kept in vector registers: with b0/b1 and the polynomial constants they do not fit the
+      // scalar file, and a spilled scalar costs a v_readlane per use)
+      sb0[k] = do_gamma ? s_sb[2 * k] : 0.0;
+      sb1[k] = do_gamma ? s_sb[2 * k + 1] : 0.0;
+#else
       sb0[k] = do_gamma ? uniform_f64(s_sb[2 * k]) : 0.0;
       sb1[k] = do_gamma ? uniform_f64(s_sb[2 * k + 1]) : 0.0;
+#endif
     }
     // software pipeline: the next item's rows (weights, gamma, counters, column words) are
     // requested before the current item's transcendental-heavy update starts
@@ -690,12 +751,33 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
 #pragma unroll
       for (int wv = 1; wv < kWaves; ++wv) v += s_red[wv][tid];
     }
-    store_row(p, par, epoch_now, v, J, rowsW, FIRST && !pending);
+    store_row(p, par, epoch_now, v, J, rowsW, !synced);
   }
 
   // workgroup 0 publishes the state the next launch starts from
   if (blockIdx.x == 0) {
     if (FIRST && pending) publish_complete(p, ctl, S, W, J, s_plam, s_peb, false);
+#ifdef TSAMD_FIRST_FAST
+    if constexpr (FIRST) {  // ... and captures what the first pass of the next SNP will need
+      NextSnp *NW = &ctl->nxt[idx & 1u];
+      const uint32_t nidx = idx + 1u;
+      if (nidx < sched_len) {
+        const uint32_t ent2 = sched[nidx];
+        const uint32_t loc2 = ent2 & 0x7fffffffu;
+        if (tid < J) {
+          const bool local = pending && loc2 == sloc;  // just finished here: not yet readable from the arrays
+          NW->lam[tid] = local ? s_plam[tid] : p.lam[(size_t)loc2 * J + tid];
+          NW->eb[tid] = local ? s_peb[tid] : p.eb[(size_t)loc2 * J + tid];
+        }
+        if (tid == 0) {
+          NW->ent = ent2;
+          NW->for_idx = nidx;
+        }
+      } else if (tid == 0) {
+        NW->for_idx = 0xffffffffu;
+      }
+    }
+#endif
     if (tid < J) {
       W->lam[tid] = s_lam[tid];
       W->eb[tid] = s_eb[tid];
@@ -765,6 +847,7 @@ __global__ void ts_begin(DevParams p, const uint32_t *sched, uint32_t n, uint32_
   carry_state(S, W, J);
   __syncthreads();
   if (threadIdx.x == 0) {
+    ctl->nxt[0].for_idx = ctl->nxt[1].for_idx = 0xffffffffu;  // captured for the previous schedule
     if (n != 0xffffffffu) {
       ctl->sched = sched;
       ctl->sched_len = n;
