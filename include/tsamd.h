@@ -86,6 +86,21 @@ const char *tsamd_last_error(const tsamd_ctx *ctx);
  * keeps the 2-bit codes packed in HBM.  The host buffer is not retained. */
 int tsamd_upload_bed(tsamd_ctx *ctx, const uint8_t *payload, uint64_t bytes_per_snp,
                      uint32_t first_loc, uint32_t n_locs);
+/* Streaming ingest.  tsamd_host_alloc gives pinned host memory; a payload that lies
+ * in it is copied by ONE strided DMA per call straight from the caller's buffer (no staging copy
+ * on the host), whereas pageable memory goes through the library's two pinned staging buffers.
+ * tsamd_upload_bed_async (pinned payloads only) returns after enqueueing: the buffer must stay
+ * unchanged until the next tsamd_synchronize(ctx) -- read the next batch of the file into a second
+ * buffer meanwhile.  Several contexts (shards) may upload from the same buffer. */
+int tsamd_host_alloc(void **ptr, uint64_t bytes);
+void tsamd_host_free(void *ptr);
+int tsamd_upload_bed_async(tsamd_ctx *ctx, const uint8_t *payload, uint64_t bytes_per_snp,
+                           uint32_t first_loc, uint32_t n_locs);
+/* replaces the genotype tallies of SNP::read_bed (src/snp.cc:203-216, reported in param.txt,
+ * :245-247): counts[c] = entries with PLINK code c (00, 01 = missing, 10, 11) among the shard's
+ * individuals in columns [first_loc, first_loc + n_locs), counted on the device.  Held-out
+ * entries count as missing: call it before tsamd_set_heldout for the reference's numbers. */
+int tsamd_genotype_counts(tsamd_ctx *ctx, uint32_t first_loc, uint32_t n_locs, uint64_t counts[4]);
 /* shard's column as ceil(shard_count/4) PLINK bytes, held-out entries shown as missing */
 int tsamd_download_bed(tsamd_ctx *ctx, uint32_t loc, uint8_t *out, uint64_t out_bytes);
 

@@ -41,6 +41,10 @@ SYMBOLS = {
     "tsamd_destroy": (None, [_vp]),
     "tsamd_last_error": (C.c_char_p, [_vp]),
     "tsamd_upload_bed": (_int, [_vp, _vp, _u64, _u32, _u32]),
+    "tsamd_upload_bed_async": (_int, [_vp, _vp, _u64, _u32, _u32]),
+    "tsamd_host_alloc": (_int, [C.POINTER(_vp), _u64]),
+    "tsamd_host_free": (None, [_vp]),
+    "tsamd_genotype_counts": (_int, [_vp, _u32, _u32, _pu64]),
     "tsamd_download_bed": (_int, [_vp, _u32, _vp, _u64]),
     "tsamd_set_heldout": (_int, [_vp, _u32, _pu32, _u32]),
     "tsamd_set_gamma": (_int, [_vp, _pd]),

@@ -124,7 +124,8 @@ struct tsamd_ctx {
   bool graphs_ready = false;
   uint64_t q = 0;  // kernels of the state-machine sequence launched so far (parity = q & 1)
   uint32_t prev_rows = 0;  // grid of the last pass kernel enqueued (row-count hint for the next)
-  std::vector<std::vector<uint32_t>> keepalive;  // host schedules of copies possibly still in flight
+  // pinned host copies of schedules whose upload may still be in flight (recycled at tsamd_synchronize)
+  std::vector<std::pair<uint32_t *, size_t>> sched_busy, sched_free;
   std::string err;
 };
 
@@ -505,6 +506,8 @@ void tsamd_destroy(tsamd_ctx *c) {
   hipFree(c->d_hreq);
   hipFree(c->d_hsums);
   if (c->h_stage) hipHostFree(c->h_stage);
+  for (auto &b : c->sched_busy) hipHostFree(b.first);
+  for (auto &b : c->sched_free) hipHostFree(b.first);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -619,41 +622,119 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   return TSAMD_OK;
 }
 
-int tsamd_upload_bed(tsamd_ctx *c, const uint8_t *payload, uint64_t bytes_per_snp, uint32_t first_loc,
-                     uint32_t n_locs) {
+// Shared by tsamd_upload_bed / _async.  Two routes:
+//  * the payload lies in pinned host memory (tsamd_host_alloc, or registered by the caller): one
+//    strided DMA straight from it (source pitch = bytes_per_snp, width = the shard's byte range,
+//    destination pitch = the column stride) -- no staging copy, the padding bytes of every column
+//    keep their "missing" fill from tsamd_create, a small kernel fixes the shard's last byte;
+//  * pageable memory: through two pinned staging buffers, the host copy of one batch overlapping
+//    the DMA of the previous one.
+static int upload_bed_impl(tsamd_ctx *c, const uint8_t *payload, uint64_t bytes_per_snp, uint32_t first_loc,
+                           uint32_t n_locs, bool wait) {
   CHECK_CTX(c);
   if (!payload) return fail(c, TSAMD_EINVAL, "null payload");
   if (bytes_per_snp != ((uint64_t)c->cfg.n + 3) / 4)
     return fail(c, TSAMD_EINVAL, "bytes_per_snp %llu != ceil(n/4) = %llu", (unsigned long long)bytes_per_snp,
                 (unsigned long long)(((uint64_t)c->cfg.n + 3) / 4));
   if (int rc = check_locs(c, first_loc, n_locs)) return rc;
+  if (n_locs == 0) return TSAMD_OK;
   HIP_TRY(c, hipSetDevice(c->dev));
   const size_t cs = c->p.colstride;
   const size_t src_off = c->n_begin / 4;
   const size_t nbytes = ((size_t)c->n_local + 3) / 4;
   const uint32_t tail = c->n_local & 3u;  // individuals in the last (partial) byte
-  const size_t batch = std::max<size_t>(1, (size_t)(32u << 20) / cs);
-  if (int rc = ensure_stage(c, std::min<size_t>(batch, n_locs) * cs)) return rc;
-  for (uint32_t j0 = 0; j0 < n_locs; j0 += (uint32_t)batch) {
-    const uint32_t nb = (uint32_t)std::min<size_t>(batch, n_locs - j0);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // staging buffer reuse
-    for (uint32_t j = 0; j < nb; ++j) {
-      uint8_t *dst = c->h_stage + (size_t)j * cs;
-      memcpy(dst, payload + (size_t)(j0 + j) * bytes_per_snp + src_off, nbytes);
-      if (tail) {  // neighbours' bits (or PLINK's zero padding) -> missing
-        const uint8_t keep = (uint8_t)((1u << (2 * tail)) - 1u);
-        dst[nbytes - 1] = (uint8_t)((dst[nbytes - 1] & keep) | (0x55u & ~keep));
+  const uint8_t keep = (uint8_t)((1u << (2 * tail)) - 1u);
+  hipPointerAttribute_t attr;
+  const bool pinned = hipPointerGetAttributes(&attr, payload) == hipSuccess && attr.type == hipMemoryTypeHost;
+  if (!pinned) (void)hipGetLastError();  // (an unknown pointer is reported as an error: pageable memory)
+  if (pinned) {
+    HIP_TRY(c, hipMemcpy2DAsync(c->p.bed + (size_t)first_loc * cs, cs, payload + src_off, bytes_per_snp, nbytes, n_locs,
+                                hipMemcpyHostToDevice, c->stream));
+    if (tail)
+      hipLaunchKernelGGL(ts_fix_tail, dim3((n_locs + 255) / 256), dim3(256), 0, c->stream, c->p.bed, (uint64_t)cs, first_loc,
+                         n_locs, (uint64_t)(nbytes - 1), (uint32_t)keep);
+  } else {
+    if (!wait) return fail(c, TSAMD_EINVAL, "tsamd_upload_bed_async needs pinned host memory (tsamd_host_alloc)");
+    const size_t batch = std::max<size_t>(1, (size_t)(32u << 20) / cs);
+    const size_t half = std::min<size_t>(batch, n_locs) * cs;
+    if (int rc = ensure_stage(c, 2 * half)) return rc;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    HIP_TRY(c, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    hipError_t e = hipSuccess;
+    uint32_t b = 0;
+    for (uint32_t j0 = 0; j0 < n_locs && e == hipSuccess; j0 += (uint32_t)batch, b ^= 1u) {
+      const uint32_t nb = (uint32_t)std::min<size_t>(batch, n_locs - j0);
+      uint8_t *stage = c->h_stage + (size_t)b * half;
+      if (j0 >= 2 * batch) e = hipEventSynchronize(ev[b]);  // this half's previous DMA
+      for (uint32_t j = 0; j < nb; ++j) {
+        uint8_t *dst = stage + (size_t)j * cs;
+        memcpy(dst, payload + (size_t)(j0 + j) * bytes_per_snp + src_off, nbytes);
+        if (tail) dst[nbytes - 1] = (uint8_t)((dst[nbytes - 1] & keep) | (0x55u & ~keep));
+        memset(dst + nbytes, 0x55, cs - nbytes);
       }
-      memset(dst + nbytes, 0x55, cs - nbytes);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(c->p.bed + (size_t)(first_loc + j0) * cs, stage, (size_t)nb * cs, hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) e = hipEventRecord(ev[b], c->stream);
     }
-    HIP_TRY(c, hipMemcpyAsync(c->p.bed + (size_t)(first_loc + j0) * cs, c->h_stage, (size_t)nb * cs,
-                              hipMemcpyHostToDevice, c->stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipEventDestroy(ev[0]);
+    hipEventDestroy(ev[1]);
+    if (e != hipSuccess) return fail(c, TSAMD_EHIP, "upload_bed: %s", hipGetErrorString(e));
   }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (wait) HIP_TRY(c, hipStreamSynchronize(c->stream));
   // a re-upload drops validation folds of those columns
   for (auto it = c->held.lower_bound(first_loc); it != c->held.end() && it->first < first_loc + n_locs;)
     it = c->held.erase(it);
   c->held_dirty = true;
+  return TSAMD_OK;
+}
+
+int tsamd_upload_bed(tsamd_ctx *c, const uint8_t *payload, uint64_t bytes_per_snp, uint32_t first_loc,
+                     uint32_t n_locs) {
+  return upload_bed_impl(c, payload, bytes_per_snp, first_loc, n_locs, true);
+}
+
+int tsamd_upload_bed_async(tsamd_ctx *c, const uint8_t *payload, uint64_t bytes_per_snp, uint32_t first_loc,
+                           uint32_t n_locs) {
+  return upload_bed_impl(c, payload, bytes_per_snp, first_loc, n_locs, false);
+}
+
+int tsamd_host_alloc(void **ptr, uint64_t bytes) {
+  if (!ptr) return fail(nullptr, TSAMD_EINVAL, "null pointer");
+  *ptr = nullptr;
+  hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocPortable);
+  if (e != hipSuccess) return fail(nullptr, e == hipErrorOutOfMemory ? TSAMD_ENOMEM : TSAMD_EHIP, "hipHostMalloc(%llu): %s",
+                                   (unsigned long long)bytes, hipGetErrorString(e));
+  return TSAMD_OK;
+}
+
+void tsamd_host_free(void *ptr) {
+  if (ptr) (void)hipHostFree(ptr);
+}
+
+int tsamd_genotype_counts(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs, uint64_t counts[4]) {
+  CHECK_CTX(c);
+  if (!counts) return fail(c, TSAMD_EINVAL, "null output");
+  if (int rc = check_locs(c, first_loc, n_locs)) return rc;
+  for (int i = 0; i < 4; ++i) counts[i] = 0;
+  if (n_locs == 0) return TSAMD_OK;
+  HIP_TRY(c, hipSetDevice(c->dev));
+  unsigned long long *d_out = (unsigned long long *)c->p.ctl->lt;  // scratch: 4 words of a buffer idle between schedules
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemsetAsync(d_out, 0, 4 * sizeof(unsigned long long), c->stream));
+  const uint32_t nwords = (c->n_local + 31u) / 32u;
+  const uint32_t gx = std::max<uint32_t>(1u, std::min<uint32_t>(64u, (nwords + 255u) / 256u));
+  for (uint32_t j0 = 0; j0 < n_locs; j0 += 65535u) {
+    const uint32_t nl = std::min<uint32_t>(65535u, n_locs - j0);
+    hipLaunchKernelGGL(ts_count_codes, dim3(gx, nl), dim3(256), 0, c->stream, c->p.bed, (uint64_t)c->p.colstride,
+                       first_loc + j0, c->n_local, d_out);
+  }
+  unsigned long long h[4] = {0, 0, 0, 0};
+  HIP_TRY(c, hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemsetAsync(d_out, 0, 4 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 4; ++i) counts[i] = h[i];
   return TSAMD_OK;
 }
 
@@ -838,12 +919,26 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   if (c->cfg.world > 1 && !c->comm && !c->p2p)
     return fail(c, TSAMD_ECOMM, "context is shard %u of %u but neither tsamd_comm_init nor tsamd_p2p_connect has been called",
                 c->cfg.rank, c->cfg.world);
-  std::vector<uint32_t> ent(n);
-  for (uint32_t i = 0; i < n; ++i) {
+  for (uint32_t i = 0; i < n; ++i)
     if (locs[i] >= c->cfg.l) return fail(c, TSAMD_EINVAL, "schedule[%u] = %u >= l", i, locs[i]);
-    ent[i] = locs[i] | (hol_mode ? 0x80000000u : 0u);
-  }
   HIP_TRY(c, hipSetDevice(c->dev));
+  // the schedule goes up through a pinned buffer: the copy is then really asynchronous
+  std::pair<uint32_t *, size_t> stage{nullptr, 0};
+  for (size_t i = 0; i < c->sched_free.size(); ++i)
+    if (c->sched_free[i].second >= n) {
+      stage = c->sched_free[i];
+      c->sched_free.erase(c->sched_free.begin() + i);
+      break;
+    }
+  if (!stage.first) {
+    size_t cap = 1024;
+    while (cap < n) cap *= 2;
+    HIP_TRY(c, hipHostMalloc((void **)&stage.first, cap * sizeof(uint32_t), hipHostMallocDefault));
+    stage.second = cap;
+  }
+  c->sched_busy.push_back(stage);
+  uint32_t *ent = stage.first;
+  for (uint32_t i = 0; i < n; ++i) ent[i] = locs[i] | (hol_mode ? 0x80000000u : 0u);
   if (n > c->sched_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     hipFree(c->d_sched);
@@ -854,8 +949,7 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
     HIP_TRY(c, hipMalloc((void **)&c->d_sched, (size_t)cap * sizeof(uint32_t)));
     c->sched_cap = cap;  // (the kernels take the pointer from Ctl, written by ts_begin)
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_sched, ent.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  c->keepalive.push_back(std::move(ent));  // until the next tsamd_synchronize
+  HIP_TRY(c, hipMemcpyAsync(c->d_sched, ent, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   // Everything that varies per SNP is read from device memory, so captured sequences of
   // 16, 8, 4, 2 and 1 SNPs are replayed as often as the schedule length needs (binary
   // decomposition: nothing is padded); results are identical to eager launches bit for bit.
@@ -898,7 +992,8 @@ int tsamd_synchronize(tsamd_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->dev));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->keepalive.clear();
+  c->sched_free.insert(c->sched_free.end(), c->sched_busy.begin(), c->sched_busy.end());
+  c->sched_busy.clear();
   if (c->p2p) {
     unsigned long long err = 0;
     HIP_TRY(c, hipMemcpy(&err, &c->xchg->error, sizeof err, hipMemcpyDeviceToHost));

@@ -44,6 +44,45 @@ __global__ void ts_export_loc(const double *lam, uint32_t K, uint32_t first_loc,
   }
 }
 
+// after a direct (unstaged) upload of columns [first_loc, first_loc + n_locs): the individuals past
+// the shard's end that share its last byte (neighbours' bits, or PLINK's zero padding) -> missing
+__global__ void ts_fix_tail(uint8_t *bed, uint64_t colstride, uint32_t first_loc, uint32_t n_locs, uint64_t last_byte,
+                            uint32_t keep_mask) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_locs) return;
+  uint8_t *b = bed + (size_t)(first_loc + j) * colstride + last_byte;
+  *b = (uint8_t)((*b & keep_mask) | (0x55u & ~keep_mask));
+}
+
+// counts of the four PLINK codes over the shard's real individuals in columns [first_loc, +n_locs)
+// (SNP::read_bed's tallies for param.txt, src/snp.cc:203-216, :245-247); one workgroup per column
+// slice, 64-bit words, three popcounts per word; out[4] accumulated with atomics.
+__global__ __launch_bounds__(256) void ts_count_codes(const uint8_t *bed, uint64_t colstride, uint32_t first_loc,
+                                                      uint32_t n_local, unsigned long long *out) {
+  __shared__ unsigned long long s_cnt[4];
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
+  const uint64_t *col = reinterpret_cast<const uint64_t *>(bed + (size_t)(first_loc + blockIdx.y) * colstride);
+  const uint32_t nwords = (n_local + 31u) / 32u;  // 32 individuals per 64-bit word
+  unsigned long long c01 = 0, c10 = 0, c11 = 0, tot = 0;
+  for (uint32_t wi = blockIdx.x * 256u + threadIdx.x; wi < nwords; wi += gridDim.x * 256u) {
+    uint64_t x = col[wi];
+    const uint32_t valid = min(32u, n_local - wi * 32u);
+    const uint64_t m = valid == 32u ? 0x5555555555555555ull : ((1ull << (2u * valid)) - 1ull) & 0x5555555555555555ull;
+    const uint64_t lo = x & m, hi = (x >> 1) & m;
+    c01 += __popcll(lo & ~hi);
+    c10 += __popcll(hi & ~lo);
+    c11 += __popcll(hi & lo);
+    tot += valid;
+  }
+  atomicAdd(&s_cnt[0], tot - c01 - c10 - c11);
+  atomicAdd(&s_cnt[1], c01);
+  atomicAdd(&s_cnt[2], c10);
+  atomicAdd(&s_cnt[3], c11);
+  __syncthreads();
+  if (threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
 // fold validation entries into the column as "missing" (01) and return the true codes
 __global__ void ts_heldout_fold(uint8_t *col, const uint32_t *local_ids, uint32_t count, uint8_t *orig) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

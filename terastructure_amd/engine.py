@@ -26,6 +26,21 @@ def _up(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint32))
 
 
+def host_alloc(nbytes):
+    """numpy uint8 view of pinned host memory (tsamd_host_alloc); free it with host_free(arr)"""
+    h = _lib.load()
+    ptr = C.c_void_p()
+    rc = h.tsamd_host_alloc(C.byref(ptr), nbytes)
+    if rc != 0:
+        raise _lib.TsamdError(rc, h.tsamd_last_error(None).decode())
+    arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,))
+    return arr
+
+
+def host_free(arr):
+    _lib.load().tsamd_host_free(C.c_void_p(arr.ctypes.data))
+
+
 class Engine:
     def __init__(self, n, l, k, device=0, rank=0, world=1, flags=0, **overrides):
         self.h = _lib.load()
@@ -76,6 +91,17 @@ class Engine:
             raise ValueError("payload must be [n_locs][bytes_per_snp]")
         self._check(self.h.tsamd_upload_bed(self.ctx, payload.ctypes.data, payload.shape[1], first_loc,
                                             payload.shape[0]))
+
+    def upload_bed_async(self, ptr, bytes_per_snp, first_loc, n_locs):
+        """payload at address ptr in pinned memory (host_alloc); valid until the next synchronize()"""
+        self._check(self.h.tsamd_upload_bed_async(self.ctx, ptr, bytes_per_snp, first_loc, n_locs))
+
+    def genotype_counts(self, first_loc=0, n_locs=None):
+        """counts of the PLINK codes (00, 01 = missing, 10, 11) over the shard's individuals"""
+        n_locs = self.l - first_loc if n_locs is None else n_locs
+        out = np.zeros(4, dtype=np.uint64)
+        self._check(self.h.tsamd_genotype_counts(self.ctx, first_loc, n_locs, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
 
     def download_bed(self, loc):
         out = np.zeros((self.shard_count + 3) // 4, dtype=np.uint8)
