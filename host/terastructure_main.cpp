@@ -25,8 +25,12 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <fcntl.h>
+
 #include <algorithm>
+#include <chrono>
 #include <map>
+#include <thread>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -121,6 +125,8 @@ struct Options {
   int device = 0;
   std::vector<int> devices;  // extension: -devices a,b,...: shard the individuals over these GPUs
   uint32_t max_iter = 0;  // extension: stop after this many iterations (0 = reference behaviour)
+  unsigned ingest_threads = 0;  // extension: reader threads of the .bed ingest (0 = up to 8)
+  bool ingest_only = false;     // extension: read the genotypes into HBM, write param.txt, stop (ingest measurement)
 };
 
 struct Run {
@@ -217,7 +223,9 @@ void usage() {
           "\t-seed <val>\t random seed\n"
           "\t-compute-beta\t compute allele frequencies given ./gamma.txt\n"
           "\t-device <id>\t HIP device ordinal (default 0)\n"
-          "\t-devices <a,b,..>\t shard the individuals over these HIP devices (one shard each)\n");
+          "\t-devices <a,b,..>\t shard the individuals over these HIP devices (one shard each)\n"
+          "\t-ingest-threads <T>\t reader threads of the .bed ingest (default: up to 8)\n"
+          "\t-ingest-only\t read the genotypes into HBM, report the rate, write param.txt and stop\n");
   fflush(stdout);
 }
 
@@ -334,30 +342,87 @@ void read_bed(Run &r) {
     fprintf(stderr, "mode problem in %s\n", r.bed_path.c_str());
     exit(-1);
   }
-  // per-byte counts of each 2-bit code, tail bits of the last byte excluded
-  uint64_t cnt[4] = {0, 0, 0, 0};
-  const size_t batch = std::max<size_t>(1, (size_t)(64u << 20) / r.bytes_per_snp);
-  std::vector<uint8_t> buf(batch * r.bytes_per_snp);
-  uint32_t loc = 0;
-  while (loc < o.l) {
-    const size_t want = std::min<size_t>(batch, o.l - loc);
-    const size_t got = fread(buf.data(), r.bytes_per_snp, want, f);
-    if (got == 0) break;
-    for (size_t j = 0; j < got; ++j) {
-      const uint8_t *col = buf.data() + j * r.bytes_per_snp;
-      for (uint32_t i = 0; i < o.n; ++i) cnt[(col[i >> 2] >> (2 * (i & 3))) & 3]++;
-    }
-    for (tsamd_ctx *c : r.ctxs) TS(r, tsamd_upload_bed(c, buf.data(), r.bytes_per_snp, loc, (uint32_t)got));
-    loc += (uint32_t)got;
-    if (loc % 20000 < got) {
-      printf("\r%d locations read", loc);
-      fflush(stdout);
-    }
-  }
   fclose(f);
-  if (loc != o.l) {
-    fprintf(stderr, "%s is truncated: %u of %u locations\n", r.bed_path.c_str(), loc, o.l);
+  // Streaming ingest: reader threads pread() a batch of columns into one of two pinned buffers
+  // while the previous batch's strided DMA into HBM is in flight (tsamd_upload_bed_async, every
+  // shard from the same buffer).  The genotype tallies of param.txt are taken on the device
+  // afterwards (tsamd_genotype_counts), not one 2-bit code at a time on the host.
+  const int fd = open(r.bed_path.c_str(), O_RDONLY);
+  if (fd < 0) {
+    fprintf(stderr, "cannot open file %s:%s\n", r.bed_path.c_str(), strerror(errno));
     exit(-1);
+  }
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (uint64_t)st.st_size < 3 + (uint64_t)o.l * r.bytes_per_snp) {
+    fprintf(stderr, "%s is truncated: %llu of %llu locations\n", r.bed_path.c_str(),
+            (unsigned long long)((st.st_size > 3 ? (uint64_t)st.st_size - 3 : 0) / r.bytes_per_snp), (unsigned long long)o.l);
+    exit(-1);
+  }
+  const size_t batch = std::max<size_t>(1, std::min<size_t>((size_t)(256u << 20) / r.bytes_per_snp, o.l));
+  uint8_t *buf[2] = {nullptr, nullptr};
+  for (auto &b : buf) {
+    void *ptr = nullptr;
+    if (tsamd_host_alloc(&ptr, batch * r.bytes_per_snp) != 0) {
+      fprintf(stderr, "error: %s\n", tsamd_last_error(nullptr));
+      exit(-1);
+    }
+    b = (uint8_t *)ptr;
+  }
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned nread = std::max(1u, std::min({o.ingest_threads ? o.ingest_threads : 8u, hw, (unsigned)batch}));
+  auto read_batch = [&](uint8_t *dst, uint32_t loc0, size_t cols) {  // columns [loc0, loc0 + cols) -> dst
+    std::vector<std::thread> th;
+    std::vector<int> bad(nread, 0);
+    for (unsigned t = 0; t < nread; ++t)
+      th.emplace_back([&, t]() {
+        const size_t c0 = cols * t / nread, c1 = cols * (t + 1) / nread;
+        size_t off = c0 * r.bytes_per_snp;
+        const size_t end = c1 * r.bytes_per_snp;
+        while (off < end) {
+          const ssize_t got = pread(fd, dst + off, std::min<size_t>(end - off, (size_t)64 << 20),
+                                    3 + (off_t)loc0 * (off_t)r.bytes_per_snp + (off_t)off);
+          if (got <= 0) {
+            bad[t] = 1;
+            return;
+          }
+          off += (size_t)got;
+        }
+      });
+    for (auto &x : th) x.join();
+    for (int b : bad)
+      if (b) {
+        fprintf(stderr, "cannot read %s\n", r.bed_path.c_str());
+        exit(-1);
+      }
+  };
+  const auto t_ing = std::chrono::steady_clock::now();
+  uint32_t loc = 0;
+  int cur = 0;
+  size_t cols = std::min<size_t>(batch, o.l);
+  read_batch(buf[cur], 0, cols);
+  while (loc < o.l) {
+    for (tsamd_ctx *c : r.ctxs) TS(r, tsamd_upload_bed_async(c, buf[cur], r.bytes_per_snp, loc, (uint32_t)cols));
+    const uint32_t next = loc + (uint32_t)cols;
+    const size_t ncols = std::min<size_t>(batch, o.l - next);
+    if (ncols) read_batch(buf[cur ^ 1], next, ncols);        // overlaps the DMA of buf[cur]
+    for (tsamd_ctx *c : r.ctxs) TS(r, tsamd_synchronize(c));  // buf[cur] is free again
+    loc = next;
+    cols = ncols;
+    cur ^= 1;
+    printf("\r%d locations read", loc);
+    fflush(stdout);
+  }
+  const double ing_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ing).count();
+  close(fd);
+  for (auto &b : buf) tsamd_host_free(b);
+  printf("\n+ ingest: %.2f GB in %.2f s (%.1f GB/s, %u reader threads)\n", (double)o.l * r.bytes_per_snp / 1e9, ing_s,
+         (double)o.l * r.bytes_per_snp / 1e9 / ing_s, nread);
+  // tallies over every shard (tail bits of a column's last byte and padding excluded by the kernel)
+  uint64_t cnt[4] = {0, 0, 0, 0};
+  for (tsamd_ctx *c : r.ctxs) {
+    uint64_t part[4];
+    TS(r, tsamd_genotype_counts(c, 0, o.l, part));
+    for (int q = 0; q < 4; ++q) cnt[q] += part[q];
   }
   r.plog_u("missing snps", cnt[1]);
   r.plog_u("0s snps", cnt[3]);  // labels swapped like the reference (src/snp.cc:207-216, :245-247)
@@ -765,6 +830,10 @@ int main(int argc, char **argv) {
       }
     } else if (!strcmp(a, "-max-iter")) {
       o.max_iter = atoi(need(a));
+    } else if (!strcmp(a, "-ingest-threads")) {
+      o.ingest_threads = (unsigned)atoi(need(a));
+    } else if (!strcmp(a, "-ingest-only")) {
+      o.ingest_only = true;
     } else {
       fprintf(stdout, "error: unknown option %s\n", a);
       exit(-1);
@@ -815,6 +884,10 @@ int main(int argc, char **argv) {
       fprintf(stderr, "unrecognized file extension\n");
       exit(-1);
     }
+  }
+  if (o.ingest_only) {
+    destroy_all(r);
+    return 0;
   }
   if (o.idfile != "") read_idfile(r);  // (src/main.cc:208)
   printf("+ initialization begin\n");

@@ -400,12 +400,8 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   // launch-time constant -- then the first item's row data.
   const bool local_rows = p.xchg_world == 0u && p.rows_from_lt == 0u;
   RowSum<BLOCK> rowsum;
-#ifdef TSAMD_FIRST_FAST
   // (first pass: only workgroup 0 needs the previous SNP's rows unless the slow path is taken)
   const bool rows_issued = local_rows && (!FIRST || blockIdx.x == 0);
-#else
-  const bool rows_issued = local_rows;
-#endif
   rowsum.issue(p.partials + (size_t)(par ^ 1u) * kMaxGrid * (2 * KT), rows_issued ? nrows_hint : 0u, 2 * KT);
   // Plain passes sweep their chunk forwards and backwards alternately (passes 2, 4, ... of a
   // SNP backwards): a pass starts on the addresses the previous one touched last (measured
@@ -415,6 +411,29 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t cnt = (i0 < end) ? (end - i0 + BLOCK - 1u) / BLOCK : 0u;  // this thread's items
   const bool rev = !FIRST && (par_arg & 2u) != 0u && p.sweep_alternate != 0u;
   auto item = [&](uint32_t t) { return rev ? i0 + (cnt - 1u - t) * BLOCK : i0 + t * BLOCK; };
+#ifdef TSAMD_PF_ALL
+  // Plain pass, small chunks (at most PFD items per thread: N <= 1M at K <= 8): EVERY item's
+  // rows are requested before the state arrives -- the whole sweep's traffic overlaps the state
+  // wait and the epilogue, after which only arithmetic is left.  What the epilogue needs (state,
+  // partial rows, its per-thread inputs) is requested first: loads return in order.
+  constexpr int PFD = (!FIRST && VEC == 2 && KT <= 8) ? 4 : 1;
+  const bool pf_all = PFD > 1 && chunk <= (uint32_t)PFD * BLOCK;  // launch-uniform
+  const PendingIn pin = load_pending(S, J);
+  WT pf[PFD > 1 ? PFD - 1 : 1][KT];
+  if (!FIRST && cnt) load_rows(item(0), bufA);
+  if constexpr (PFD > 1) {
+    if (pf_all && cnt) {
+#pragma unroll
+      for (int d = 1; d < PFD; ++d) load_rows(item(min((uint32_t)d, cnt - 1u)), pf[d - 1]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
+  const uint32_t siters = S->iters, snrows = S->nrows;
+  const uint32_t sched_len = ctl->sched_len;
+  const uint32_t *sched = ctl->sched;
+#else
   if (!FIRST && cnt) load_rows(item(0), bufA);
   __builtin_amdgcn_sched_barrier(0);
 
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t sched_len = ctl->sched_len;
   const uint32_t *sched = ctl->sched;
   const PendingIn pin = load_pending(S, J);
-#ifdef TSAMD_FIRST_FAST
+#endif
   // first pass: what it needs about the new SNP was captured one SNP ahead (NextSnp); both slots
   // are requested with the state, the one whose for_idx matches is used
   uint32_t nx_for[2] = {0xffffffffu, 0xffffffffu}, nx_ent[2] = {0u, 0u};
@@ -437,11 +456,29 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
       nx_eb[q] = ctl->nxt[q].eb[tid < J ? tid : 0u];
     }
   }
-#endif
   // plain pass: the location is known as soon as the state is (it only changes in a first
   // pass), so the first column word is requested now and arrives during the epilogue
   uint32_t word_early = 0;
+#ifdef TSAMD_PF_ALL
+  // The column bits of a wave's item are 32 contiguous bytes (64 lanes x 2 individuals x 2 bits):
+  // ONE scalar load per wave and item -- it does not queue behind the vector loads above
+  // (separate counter), so it is there when the epilogue ends; each lane then picks its word.
+  uint32_t pfw[PFD][8];
+  if constexpr (PFD > 1) {
+    if (pf_all && cnt) {
+      const uint32_t *colS = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride);
+#pragma unroll
+      for (int d = 0; d < PFD; ++d) {
+        const uint32_t w0 = __builtin_amdgcn_readfirstlane(item(min((uint32_t)d, cnt - 1u)) / kItemsPerWord);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pfw[d][q] = colS[w0 + q];
+      }
+    }
+  }
+  if (!FIRST && cnt && !pf_all)
+#else
   if (!FIRST && cnt)
+#endif
     word_early = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride)[item(0) / kItemsPerWord];
   __builtin_amdgcn_sched_barrier(0);
   const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
@@ -456,7 +493,6 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   TSAMD_TR(1);
   const bool pending = svalid != 0u && sdone == 0u;
   const unsigned long long epoch_now = S->epoch + 1ull;
-#ifdef TSAMD_FIRST_FAST
   // First pass, fast path: the new SNP's entry and values come from NextSnp, and the previous
   // SNP's epilogue (row sum, update_lambda, estimate_beta) is only needed for publishing its final
   // values -- workgroup 0's job; every other workgroup goes straight to the sweep.  Slow path (the
@@ -470,9 +506,6 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   }
   const bool first_fast = FIRST && nx_sel >= 0;
   const bool need_epilogue = pending && (!first_fast || blockIdx.x == 0);
-#else
-  const bool need_epilogue = pending;
-#endif
   bool synced = false;  // sharded peer-to-peer: this workgroup has waited for its peers' previous rows
   if (p.xchg_world) {
     publish_progress(p, epoch_now);
@@ -521,7 +554,6 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     iters = 1u;
     do_gamma = svalid != 0u && shol == 0u;
     prev_loc = sloc;
-#ifdef TSAMD_FIRST_FAST
     if (first_fast) {
       const uint32_t ent = nx_sel ? nx_ent[1] : nx_ent[0];
       loc = ent & 0x7fffffffu;
@@ -532,7 +564,6 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
         s_eb[tid] = nx_sel ? nx_eb[1] : nx_eb[0];
       }
     } else
-#endif
     {
       const uint32_t ent = sched[idx];
       loc = ent & 0x7fffffffu;
@@ -614,6 +645,28 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     };
     WT bufB[KT];
     uint32_t wordA = 0, wordB = 0;
+#ifdef TSAMD_PF_ALL
+    bool swept = false;
+    if constexpr (PFD > 1) {
+      if (pf_all) {
+        swept = true;
+        if (cnt) {
+          const uint32_t lw = (tid >> 3) & 7u;  // this lane's word among the wave's eight
+          auto pick = [&](const uint32_t (&sw)[8]) {
+            const uint32_t a = (lw & 1u) ? sw[1] : sw[0], b = (lw & 1u) ? sw[3] : sw[2];
+            const uint32_t c = (lw & 1u) ? sw[5] : sw[4], e = (lw & 1u) ? sw[7] : sw[6];
+            const uint32_t ab = (lw & 2u) ? b : a, ce = (lw & 2u) ? e : c;
+            return (lw & 4u) ? ce : ab;
+          };
+          consume(item(0), bufA, pick(pfw[0]));
+#pragma unroll
+          for (int d = 1; d < PFD; ++d)
+            if ((uint32_t)d < cnt) consume(item((uint32_t)d), pf[d - 1], pick(pfw[d]));
+        }
+      }
+    }
+    if (!swept)
+#endif
     if (cnt) {
       wordA = word_early;
       uint32_t t = 0;
@@ -641,15 +694,10 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     double sb0[KT], sb1[KT];  // exp(Elogbeta) of the previous SNP's last pass (wave-uniform)
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-#ifdef TSAMD_SB_VGPR
       // (kept in vector registers: with b0/b1 and the polynomial constants they do not fit the
       // scalar file, and a spilled scalar costs a v_readlane per use)
       sb0[k] = do_gamma ? s_sb[2 * k] : 0.0;
       sb1[k] = do_gamma ? s_sb[2 * k + 1] : 0.0;
-#else
-      sb0[k] = do_gamma ? uniform_f64(s_sb[2 * k]) : 0.0;
-      sb1[k] = do_gamma ? uniform_f64(s_sb[2 * k + 1]) : 0.0;
-#endif
     }
     // software pipeline: the next item's rows (weights, gamma, counters, column words) are
     // requested before the current item's transcendental-heavy update starts
@@ -757,7 +805,6 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   // workgroup 0 publishes the state the next launch starts from
   if (blockIdx.x == 0) {
     if (FIRST && pending) publish_complete(p, ctl, S, W, J, s_plam, s_peb, false);
-#ifdef TSAMD_FIRST_FAST
     if constexpr (FIRST) {  // ... and captures what the first pass of the next SNP will need
       NextSnp *NW = &ctl->nxt[idx & 1u];
       const uint32_t nidx = idx + 1u;
@@ -777,7 +824,6 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
         NW->for_idx = 0xffffffffu;
       }
     }
-#endif
     if (tid < J) {
       W->lam[tid] = s_lam[tid];
       W->eb[tid] = s_eb[tid];
