@@ -285,7 +285,7 @@ __device__ __forceinline__ double row_partial_sum_xchg(const double *rows, uint3
 // src/snpsamplinge.cc:721-740).  The population with the largest a gets exp(0), so w never
 // underflows for all k at once.
 template <int KT>
-__device__ __forceinline__ void gamma_to_w(const double (&g)[KT], double (&w)[KT]) {
+__device__ __forceinline__ void gamma_to_w(const double (&g)[KT], double (&w)[KT], const double *exp_tab = nullptr) {
   double z[KT], a[KT];
   double amax = -1.0e300;
 #pragma unroll
@@ -294,7 +294,7 @@ __device__ __forceinline__ void gamma_to_w(const double (&g)[KT], double (&w)[KT
     amax = fmax(amax, a[k]);
   }
 #pragma unroll
-  for (int k = 0; k < KT; ++k) w[k] = z[k] * exp_nonpos(a[k] - amax);
+  for (int k = 0; k < KT; ++k) w[k] = z[k] * (exp_tab ? exp_nonpos_tab(a[k] - amax, exp_tab) : exp_nonpos(a[k] - amax));
 }
 
 // SVI step for one individual (update_gamma + update_rho_indiv,
@@ -371,6 +371,10 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   __shared__ double s_diff[J];
   __shared__ double s_red[kWaves][J];
   __shared__ double s_fin[BLOCK];
+#ifdef TSAMD_EXP_TAB
+  __shared__ double s_exp2[FIRST ? 64 : 1];
+  if (FIRST && threadIdx.x < 64) s_exp2[threadIdx.x] = kExp2Tab[threadIdx.x];  // (a barrier follows before its first use)
+#endif
 
   Ctl *ctl = p.ctl;
   const State *S = &ctl->st[par ^ 1u];
@@ -463,6 +467,16 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   // The column bits of a wave's item are 32 contiguous bytes (64 lanes x 2 individuals x 2 bits):
   // ONE scalar load per wave and item -- it does not queue behind the vector loads above
   // (separate counter), so it is there when the epilogue ends; each lane then picks its word.
+#ifdef TSAMD_PF_VWORD
+  uint32_t pfw[PFD][1];
+  if constexpr (PFD > 1) {
+    if (pf_all && cnt) {
+      const uint32_t *colS = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride);
+#pragma unroll
+      for (int d = 0; d < PFD; ++d) pfw[d][0] = colS[item(min((uint32_t)d, cnt - 1u)) / kItemsPerWord];
+    }
+  }
+#else
   uint32_t pfw[PFD][8];
   if constexpr (PFD > 1) {
     if (pf_all && cnt) {
@@ -475,6 +489,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
       }
     }
   }
+#endif
   if (!FIRST && cnt && !pf_all)
 #else
   if (!FIRST && cnt)
@@ -652,12 +667,16 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
         swept = true;
         if (cnt) {
           const uint32_t lw = (tid >> 3) & 7u;  // this lane's word among the wave's eight
+#ifdef TSAMD_PF_VWORD
+          auto pick = [&](const uint32_t (&sw)[1]) { (void)lw; return sw[0]; };
+#else
           auto pick = [&](const uint32_t (&sw)[8]) {
             const uint32_t a = (lw & 1u) ? sw[1] : sw[0], b = (lw & 1u) ? sw[3] : sw[2];
             const uint32_t c = (lw & 1u) ? sw[5] : sw[4], e = (lw & 1u) ? sw[7] : sw[6];
             const uint32_t ab = (lw & 2u) ? b : a, ce = (lw & 2u) ? e : c;
             return (lw & 4u) ? ce : ab;
           };
+#endif
           consume(item(0), bufA, pick(pfw[0]));
 #pragma unroll
           for (int d = 1; d < PFD; ++d)
@@ -716,7 +735,22 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     CT cv{}, cv_n{};
     uint32_t word = 0, pword = 0, word_n = 0, pword_n = 0;
     if (i0 < end) load_item(i0, wv, gv, cv, word, pword);
+#ifdef TSAMD_PRIO_FLIP
+    // two workgroups share a compute unit and the hardware favours the older one, which then
+    // finishes early and leaves the younger alone at one wave per SIMD: the younger half of the
+    // grid gets priority for the first half of its items, the older half for its second half
+    const bool younger = blockIdx.x >= (gridDim.x >> 1);
+    uint32_t it2 = 0;
+    const uint32_t cnt_u = __builtin_amdgcn_readfirstlane(cnt);
+#endif
     for (uint32_t i = i0; i < end; i += BLOCK) {
+#ifdef TSAMD_PRIO_FLIP
+      if ((it2 < cnt_u) == younger)
+        __builtin_amdgcn_s_setprio(1);
+      else
+        __builtin_amdgcn_s_setprio(0);
+      it2 += 2u;
+#endif
       const uint32_t inext = (i + BLOCK < end) ? i + BLOCK : i;  // clamped: static load counts
       load_item(inext, wv_n, gv_n, cv_n, word_n, pword_n);
       __builtin_amdgcn_sched_barrier(0);
@@ -738,7 +772,11 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
             gamma_step_one<KT>(g[v], w[v], sb0, sb1, mom, dad, cn[v], p);
 #endif
 #if !defined(TSAMD_ABL) || TSAMD_ABL == 3
+#ifdef TSAMD_EXP_TAB
+            gamma_to_w<KT>(g[v], w[v], s_exp2);
+#else
             gamma_to_w<KT>(g[v], w[v]);
+#endif
 #endif
           }
         }
