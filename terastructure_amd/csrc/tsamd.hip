@@ -88,6 +88,7 @@ struct tsamd_ctx {
   uint32_t n_begin = 0, n_local = 0, npad = 0;
   bool wide = false;  // K above TSAMD_SPECIALIZED_K: run-time-K fallback kernels (tsamd_wide_kernels.h)
   uint32_t grid = 0, block = 256, grid_first = 0, first_vec = 1;  // plain-pass and first-pass launch geometry
+  bool prefetch_all = false;  // plain pass: every item of a thread requested before the state arrives (chunk <= 4 x 512)
   DevParams p{};
   uint32_t *d_sched = nullptr;
   uint32_t sched_cap = 0;
@@ -198,7 +199,8 @@ int enqueue_pass(tsamd_ctx *c, uint32_t pass) {
   } else if (first)
     kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p, par_arg, hint);
   else
-    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p, par_arg, hint);
+    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block | (c->prefetch_all ? kLaunchPrefetchAll : 0u), c->stream, c->p, par_arg,
+                         hint);
   if (!c->wide) c->prev_rows = first ? c->grid_first : c->grid;
   if (c->split && !c->p2p) {  // (peer-to-peer: every workgroup has already pushed its row to every rank)
     hipLaunchKernelGGL(ts_reduce_rows, dim3(1), dim3(256), 0, c->stream, c->p, par);
@@ -305,6 +307,7 @@ int build_graph(tsamd_ctx *c, uint32_t level, uint32_t par0) {
   if (e != hipSuccess) return fail(c, TSAMD_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
   slot.graph = g;
   HIP_TRY(c, hipGraphInstantiate(&slot.exec, slot.graph, nullptr, nullptr, 0));
+  if (hipGraphUpload(slot.exec, c->stream) != hipSuccess) (void)hipGetLastError();  // (optional in this runtime)
   return TSAMD_OK;
 }
 
@@ -370,6 +373,8 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
   c->block = block;
   c->first_vec = env_u32("TSAMD_FIRST_VEC", 1) == 2 ? 2 : 1;
   geometry(p.npairs, block, env_u32("TSAMD_GRID", 256), p.chunk, c->grid);
+  c->prefetch_all = block == 512u && (int)c->cfg.k <= kPrefetchAllMaxK && p.chunk <= kPrefetchAllItems * 512u &&
+                    env_u32("TSAMD_PF", 0) != 0u;
   // first pass: exactly as many workgroups as are resident at once (one round; the kernel is
   // register-bound, so that is 2 per compute unit at K = 8 and 1 from K = 12 on)
   uint32_t first_target = 512;
@@ -380,6 +385,26 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
       first_target = (uint32_t)prop.multiProcessorCount * (uint32_t)std::min(nb, 4);
   }
   geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", first_target), p.chunk_first, c->grid_first);
+  // Uneven static split of the first pass (TSAMD_FIRST_SKEW="even1,odd1,even2,odd2", relative weights of a
+  // workgroup of the first / second dispatch round with an even / odd index; default: even split).
+  p.first_g1 = c->grid_first;
+  for (uint32_t &v : p.first_size) v = p.chunk_first;
+  {
+    const char *sk = getenv("TSAMD_FIRST_SKEW");
+    int cus = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->dev) == hipSuccess) cus = prop.multiProcessorCount;
+    double wgt[4];
+    if (sk && *sk && cus > 0 && c->grid_first > (uint32_t)cus &&
+        sscanf(sk, "%lf,%lf,%lf,%lf", &wgt[0], &wgt[1], &wgt[2], &wgt[3]) == 4 && wgt[0] > 0 && wgt[1] > 0 && wgt[2] > 0 &&
+        wgt[3] > 0) {
+      const uint32_t g1 = (uint32_t)cus, g2 = c->grid_first - g1, nitems = p.npad / c->first_vec;
+      const double units = ((g1 + 1) / 2) * wgt[0] + (g1 / 2) * wgt[1] + ((g2 + 1) / 2) * wgt[2] + (g2 / 2) * wgt[3];
+      p.first_g1 = g1;
+      for (int q = 0; q < 4; ++q)
+        p.first_size[q] = std::max<uint32_t>(64u, (uint32_t)std::ceil(wgt[q] * nitems / units / 64.0) * 64u);
+    }
+  }
 }
 
 // Switch the kernel sequence to the exchange buffer (rows + epoch flags pushed by every
@@ -984,6 +1009,17 @@ int tsamd_prepare(tsamd_ctx *c) {
   if (c->cfg.world > 1 && !c->comm && !c->p2p) return TSAMD_OK;  // exchange not chosen yet: nothing to capture
   if (!graphs_allowed(c)) return TSAMD_OK;
   if (int rc = ensure_graphs(c)) return rc;
+  // One dry replay of every graph: whatever the runtime does on a graph's first launch happens
+  // here.  With no schedule in progress every kernel of the sequence only carries the state
+  // forward (sharded: all ranks call tsamd_prepare alike, so the launch sequences stay aligned).
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  hipLaunchKernelGGL(ts_begin, dim3(1), dim3(256), 0, c->stream, c->p, (const uint32_t *)c->d_sched, 0u, next_parity(c), 0u);
+  for (uint32_t level = 0; level < kGraphLevels; ++level)
+    for (uint32_t par0 = 0; par0 < 2; ++par0) {
+      if ((uint32_t)(c->q & 1u) != par0) enqueue_begin(c, 0xffffffffu, false);
+      HIP_TRY(c, hipGraphLaunch(c->graphs[level][par0].exec, c->stream));
+      c->q += (uint64_t)(1u << level) * kernels_per_snp(c);
+    }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSAMD_OK;
 }
@@ -1367,7 +1403,7 @@ int tsamd_probe_stream(tsamd_ctx *c, uint32_t reps, double *read_us, double *rmw
       if (r == 3u) (void)hipEventRecord(e0, c->stream);
       if (rmw)
         hipLaunchKernelGGL(ts_probe_rmw, dim3(c->grid_first), dim3(256), 0, c->stream, c->p.w, c->p.gam, K, c->npad,
-                           chunk_first, 1.0);
+                           chunk_first, 1.0, env_u32("TSAMD_PROBE_THINK_NS", 0) / 10u);
       else
         hipLaunchKernelGGL(ts_probe_read, dim3(c->grid), dim3(c->block), 0, c->stream, c->p.w, K, c->npad, chunk_pairs,
                            c->p.sweep_alternate ? (r & 1u) : 0u, sink);

@@ -99,6 +99,11 @@ struct DevParams {
   uint32_t npairs;     // npad / 2
   uint32_t chunk;      // items (pairs of individuals) per workgroup of the plain pass kernel
   uint32_t chunk_first; // items (individuals, or pairs with TSAMD_FIRST_VEC=2) per workgroup of the first pass
+  // first pass, uneven static split (configure_launch): workgroups [0, first_g1) are the first dispatch round
+  // (one per compute unit), the rest the second; first_size[2 * round + (workgroup index odd)] = items of a
+  // workgroup of that class.  All four equal chunk_first = the even split.
+  uint32_t first_g1;
+  uint32_t first_size[4];
   uint32_t K;
   uint32_t max_inner;
   uint32_t sweep_alternate; // plain passes alternate their sweep direction (L2 reuse); TSAMD_SWEEP=0 disables

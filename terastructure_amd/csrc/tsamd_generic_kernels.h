@@ -172,9 +172,13 @@ __global__ __launch_bounds__(1024) void ts_probe_read(const double *w, uint32_t 
 }
 
 __global__ __launch_bounds__(256) void ts_probe_rmw(double *w, double *gam, uint32_t K, uint32_t npad, uint32_t chunk,
-                                                    double one) {
+                                                    double one, uint32_t think_ticks) {
   const uint32_t begin = blockIdx.x * chunk, end = min(begin + chunk, npad);
   for (uint32_t i = begin + threadIdx.x; i < end; i += 256u) {
+    if (think_ticks) {  // stand-in for the arithmetic between an item's loads and stores (10 ns ticks): de-phases
+      const unsigned long long t0 = wall_clock64();  // the workgroups' read and write bursts like the real kernel
+      while (wall_clock64() - t0 < think_ticks) __builtin_amdgcn_s_sleep(2);
+    }
     for (uint32_t k0 = 0; k0 < K; k0 += 8u) {
       double a[8], b[8];
 #pragma unroll

@@ -351,8 +351,9 @@ struct Lanes<2> {
 #ifndef TSAMD_FIRST_WAVES
 #define TSAMD_FIRST_WAVES 1
 #endif
-template <int KT, bool FIRST, int BLOCK, int VEC>
+template <int KT, bool FIRST, int BLOCK, int VEC, int PFD = 1>
 __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1) void ts_pass(DevParams p, uint32_t par_arg, uint32_t nrows_hint) {
+  static_assert(PFD == 1 || (!FIRST && VEC == 2), "prefetch-all is a plain-pass variant");
   // par_arg: bit 0 = launch parity (state / partial-row slot written), bit 1 = plain pass sweeps
   // its chunk backwards (set for the odd passes of a SNP, a property of the pass, not of the
   // launch parity: any cut of a schedule into calls or graphs gives the same summation order)
@@ -379,6 +380,9 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   Ctl *ctl = p.ctl;
   const State *S = &ctl->st[par ^ 1u];
   State *W = &ctl->st[par];
+#ifdef TSAMD_WGTIME
+  const unsigned long long wg_t0 = wall_clock64();
+#endif
 #ifdef TSAMD_TRACE
   unsigned long long tr[6];
   tr[0] = wall_clock64();
@@ -389,8 +393,14 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t tid = threadIdx.x;
   const size_t np = p.npad;
   const uint32_t nitems = p.npad / VEC;
-  const uint32_t chunk = FIRST ? p.chunk_first : p.chunk;
-  const uint32_t begin = blockIdx.x * chunk;
+  uint32_t chunk = p.chunk, begin = blockIdx.x * p.chunk;
+  if constexpr (FIRST) {  // (uneven static split by dispatch round and workgroup parity, tsamd_device.h)
+    const uint32_t g1 = p.first_g1, r2 = blockIdx.x >= g1 ? 1u : 0u;
+    const uint32_t bb = r2 ? blockIdx.x - g1 : blockIdx.x;
+    const uint32_t base = r2 ? ((g1 + 1u) / 2u) * p.first_size[0] + (g1 / 2u) * p.first_size[1] : 0u;
+    begin = base + ((bb + 1u) / 2u) * p.first_size[2 * r2] + (bb / 2u) * p.first_size[2 * r2 + 1];
+    chunk = p.first_size[2 * r2 + (bb & 1u)];
+  }
   const uint32_t end = min(begin + chunk, nitems);
 
   auto load_rows = [&](uint32_t i, WT (&wv)[KT]) {
@@ -415,20 +425,21 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t cnt = (i0 < end) ? (end - i0 + BLOCK - 1u) / BLOCK : 0u;  // this thread's items
   const bool rev = !FIRST && (par_arg & 2u) != 0u && p.sweep_alternate != 0u;
   auto item = [&](uint32_t t) { return rev ? i0 + (cnt - 1u - t) * BLOCK : i0 + t * BLOCK; };
-#ifdef TSAMD_PF_ALL
-  // Plain pass, small chunks (at most PFD items per thread: N <= 1M at K <= 8): EVERY item's
-  // rows are requested before the state arrives -- the whole sweep's traffic overlaps the state
-  // wait and the epilogue, after which only arithmetic is left.  What the epilogue needs (state,
-  // partial rows, its per-thread inputs) is requested first: loads return in order.
-  constexpr int PFD = (!FIRST && VEC == 2 && KT <= 8) ? 4 : 1;
-  const bool pf_all = PFD > 1 && chunk <= (uint32_t)PFD * BLOCK;  // launch-uniform
+  // What the epilogue needs (partial rows above, its per-thread inputs here) is requested before
+  // the sweep's own data: loads return in order.  The sweep loads below are issued
+  // unconditionally with clamped indices (a thread past the end of the last chunk re-reads the
+  // array's last item): a load inside a branch would make every later wait conservative.
   const PendingIn pin = load_pending(S, J);
+  auto item_or_last = [&](uint32_t t) { return cnt ? item(min(t, cnt - 1u)) : min(i0, nitems - 1u); };
+  // PFD > 1 (plain pass, at most PFD items per thread: N <= 1M at K <= 8): EVERY item's rows are
+  // requested before the state arrives -- the whole sweep's traffic overlaps the state wait and the
+  // epilogue, after which only arithmetic is left.
   WT pf[PFD > 1 ? PFD - 1 : 1][KT];
-  if (!FIRST && cnt) load_rows(item(0), bufA);
-  if constexpr (PFD > 1) {
-    if (pf_all && cnt) {
+  if constexpr (!FIRST) {
+    load_rows(item_or_last(0), bufA);
+    if constexpr (PFD > 1) {
 #pragma unroll
-      for (int d = 1; d < PFD; ++d) load_rows(item(min((uint32_t)d, cnt - 1u)), pf[d - 1]);
+      for (int d = 1; d < PFD; ++d) load_rows(item_or_last((uint32_t)d), pf[d - 1]);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -437,16 +448,6 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t siters = S->iters, snrows = S->nrows;
   const uint32_t sched_len = ctl->sched_len;
   const uint32_t *sched = ctl->sched;
-#else
-  if (!FIRST && cnt) load_rows(item(0), bufA);
-  __builtin_amdgcn_sched_barrier(0);
-
-  const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
-  const uint32_t siters = S->iters, snrows = S->nrows;
-  const uint32_t sched_len = ctl->sched_len;
-  const uint32_t *sched = ctl->sched;
-  const PendingIn pin = load_pending(S, J);
-#endif
   // first pass: what it needs about the new SNP was captured one SNP ahead (NextSnp); both slots
   // are requested with the state, the one whose for_idx matches is used
   uint32_t nx_for[2] = {0xffffffffu, 0xffffffffu}, nx_ent[2] = {0u, 0u};
@@ -463,38 +464,32 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   // plain pass: the location is known as soon as the state is (it only changes in a first
   // pass), so the first column word is requested now and arrives during the epilogue
   uint32_t word_early = 0;
-#ifdef TSAMD_PF_ALL
-  // The column bits of a wave's item are 32 contiguous bytes (64 lanes x 2 individuals x 2 bits):
-  // ONE scalar load per wave and item -- it does not queue behind the vector loads above
-  // (separate counter), so it is there when the epilogue ends; each lane then picks its word.
+  // PFD > 1: the column bits of a wave's item are 32 contiguous bytes (64 lanes x 2 individuals x 2
+  // bits): ONE scalar load per wave and item -- it does not queue behind the vector loads above
+  // (separate counter); each lane then picks its word.  (TSAMD_PF_VWORD: per-lane vector loads.)
 #ifdef TSAMD_PF_VWORD
-  uint32_t pfw[PFD][1];
-  if constexpr (PFD > 1) {
-    if (pf_all && cnt) {
-      const uint32_t *colS = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride);
-#pragma unroll
-      for (int d = 0; d < PFD; ++d) pfw[d][0] = colS[item(min((uint32_t)d, cnt - 1u)) / kItemsPerWord];
-    }
-  }
+  constexpr int kPfWords = 1;
 #else
-  uint32_t pfw[PFD][8];
-  if constexpr (PFD > 1) {
-    if (pf_all && cnt) {
-      const uint32_t *colS = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride);
+  constexpr int kPfWords = 8;
+#endif
+  uint32_t pfw[PFD][kPfWords];
+  if constexpr (!FIRST) {
+    const uint32_t *colS = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride);
+    if constexpr (PFD > 1) {
 #pragma unroll
       for (int d = 0; d < PFD; ++d) {
-        const uint32_t w0 = __builtin_amdgcn_readfirstlane(item(min((uint32_t)d, cnt - 1u)) / kItemsPerWord);
+#ifdef TSAMD_PF_VWORD
+        pfw[d][0] = colS[item_or_last((uint32_t)d) / kItemsPerWord];
+#else
+        const uint32_t w0 = __builtin_amdgcn_readfirstlane(item_or_last((uint32_t)d) / kItemsPerWord);
 #pragma unroll
         for (int q = 0; q < 8; ++q) pfw[d][q] = colS[w0 + q];
+#endif
       }
+    } else {
+      word_early = colS[item_or_last(0) / kItemsPerWord];
     }
   }
-#endif
-  if (!FIRST && cnt && !pf_all)
-#else
-  if (!FIRST && cnt)
-#endif
-    word_early = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride)[item(0) / kItemsPerWord];
   __builtin_amdgcn_sched_barrier(0);
   const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                         : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
@@ -660,32 +655,25 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     };
     WT bufB[KT];
     uint32_t wordA = 0, wordB = 0;
-#ifdef TSAMD_PF_ALL
-    bool swept = false;
     if constexpr (PFD > 1) {
-      if (pf_all) {
-        swept = true;
-        if (cnt) {
-          const uint32_t lw = (tid >> 3) & 7u;  // this lane's word among the wave's eight
+      if (cnt) {
 #ifdef TSAMD_PF_VWORD
-          auto pick = [&](const uint32_t (&sw)[1]) { (void)lw; return sw[0]; };
+        auto pick = [&](const uint32_t (&sw)[1]) { return sw[0]; };
 #else
-          auto pick = [&](const uint32_t (&sw)[8]) {
-            const uint32_t a = (lw & 1u) ? sw[1] : sw[0], b = (lw & 1u) ? sw[3] : sw[2];
-            const uint32_t c = (lw & 1u) ? sw[5] : sw[4], e = (lw & 1u) ? sw[7] : sw[6];
-            const uint32_t ab = (lw & 2u) ? b : a, ce = (lw & 2u) ? e : c;
-            return (lw & 4u) ? ce : ab;
-          };
+        const uint32_t lw = (tid >> 3) & 7u;  // this lane's word among the wave's eight
+        auto pick = [&](const uint32_t (&sw)[8]) {
+          const uint32_t a = (lw & 1u) ? sw[1] : sw[0], b = (lw & 1u) ? sw[3] : sw[2];
+          const uint32_t c = (lw & 1u) ? sw[5] : sw[4], e = (lw & 1u) ? sw[7] : sw[6];
+          const uint32_t ab = (lw & 2u) ? b : a, ce = (lw & 2u) ? e : c;
+          return (lw & 4u) ? ce : ab;
+        };
 #endif
-          consume(item(0), bufA, pick(pfw[0]));
+        consume(item(0), bufA, pick(pfw[0]));
 #pragma unroll
-          for (int d = 1; d < PFD; ++d)
-            if ((uint32_t)d < cnt) consume(item((uint32_t)d), pf[d - 1], pick(pfw[d]));
-        }
+        for (int d = 1; d < PFD; ++d)
+          if ((uint32_t)d < cnt) consume(item((uint32_t)d), pf[d - 1], pick(pfw[d]));
       }
-    }
-    if (!swept)
-#endif
+    } else
     if (cnt) {
       wordA = word_early;
       uint32_t t = 0;
@@ -877,6 +865,20 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
       W->epoch = epoch_now;
     }
   }
+#ifdef TSAMD_WGTIME
+  {  // start / finish stamps of the workgroups of one first pass and one plain pass, kept in the unused tail of
+     // the partial-row buffer and printed by workgroup 0 of the next first pass
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(p.partials + (size_t)2 * kMaxGrid * 2 * TSAMD_MAX_K) - 4 * kMaxGrid;
+    if (tid == 0 && idx == 41u && (FIRST || iters == 5u)) {
+      stamps[(FIRST ? 0 : 2) * kMaxGrid + blockIdx.x] = wall_clock64();
+      stamps[(FIRST ? 1 : 3) * kMaxGrid + blockIdx.x] = wg_t0;
+    }
+    if (FIRST && tid == 0 && idx == 42u && blockIdx.x == 0) {
+      for (uint32_t b = 0; b < gridDim.x; ++b) printf("wgtime %u %llu %llu\n", b, stamps[kMaxGrid + b], stamps[b]);
+      for (uint32_t b = 0; b < 256u; ++b) printf("wgplain %u %llu %llu\n", b, stamps[3 * kMaxGrid + b], stamps[2 * kMaxGrid + b]);
+    }
+  }
+#endif
 #ifdef TSAMD_TRACE
   TSAMD_TR(5);
   if (blockIdx.x == 0 && tid == 0 && idx >= 40u && idx < 44u)
@@ -983,6 +985,9 @@ __global__ __launch_bounds__(kBlock) void ts_refresh_w(DevParams p) {
 // Host-side launcher of the K-specialised kernels; one translation unit per K
 // (tsamd_inst.hip compiled with -DTSAMD_K=<k>) defines tsamd::launch_k<k>.
 enum LaunchWhich { kLaunchPass = 0, kLaunchFirst = 1, kLaunchRefresh = 2 };
+constexpr uint32_t kLaunchPrefetchAll = 0x10000u;  // flag in the block argument: ts_pass<K, false, 512, 2, 4>
+constexpr int kPrefetchAllMaxK = 8;                // (its 4 x K x 16-byte row buffers fit two waves per SIMD up to here)
+constexpr uint32_t kPrefetchAllItems = 4;
 using LaunchFn = void (*)(int which, uint32_t grid, uint32_t block, hipStream_t stream, const DevParams &p,
                           uint32_t par, uint32_t nrows_hint);
 

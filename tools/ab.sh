@@ -6,6 +6,6 @@ run() { # variant
   v=$1
   L="TSAMD_X=1"; [ -n "$v" ] && L="TSAMD_LIB=$GRAFT_REPO_ROOT/terastructure_amd/lib/variants/libtsamd_$v.so"
   echo "### variant '${v:-default}' $ARGS"
-  bash tools/prof.sh v${v:-default} $L -- $ARGS --cpu-seconds 0 --no-profile 2>&1 | grep -E "ts_pass<|^value" | cut -c1-160
+  bash tools/prof.sh v${v:-default} $L -- $ARGS --cpu-seconds 0 --no-profile 2>&1 | grep -E "ts_pass<|^value" | cut -c1-190
 }
 for rep in 1 2; do for v in "" $VARIANTS; do run "$v"; done; done
