@@ -88,7 +88,6 @@ struct tsamd_ctx {
   uint32_t n_begin = 0, n_local = 0, npad = 0;
   bool wide = false;  // K above TSAMD_SPECIALIZED_K: run-time-K fallback kernels (tsamd_wide_kernels.h)
   uint32_t grid = 0, block = 256, grid_first = 0, first_vec = 1;  // plain-pass and first-pass launch geometry
-  bool prefetch_all = false;  // plain pass: every item of a thread requested before the state arrives (chunk <= 4 x 512)
   DevParams p{};
   uint32_t *d_sched = nullptr;
   uint32_t sched_cap = 0;
@@ -199,8 +198,7 @@ int enqueue_pass(tsamd_ctx *c, uint32_t pass) {
   } else if (first)
     kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p, par_arg, hint);
   else
-    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block | (c->prefetch_all ? kLaunchPrefetchAll : 0u), c->stream, c->p, par_arg,
-                         hint);
+    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p, par_arg, hint);
   if (!c->wide) c->prev_rows = first ? c->grid_first : c->grid;
   if (c->split && !c->p2p) {  // (peer-to-peer: every workgroup has already pushed its row to every rank)
     hipLaunchKernelGGL(ts_reduce_rows, dim3(1), dim3(256), 0, c->stream, c->p, par);
@@ -373,8 +371,6 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
   c->block = block;
   c->first_vec = env_u32("TSAMD_FIRST_VEC", 1) == 2 ? 2 : 1;
   geometry(p.npairs, block, env_u32("TSAMD_GRID", 256), p.chunk, c->grid);
-  c->prefetch_all = block == 512u && (int)c->cfg.k <= kPrefetchAllMaxK && p.chunk <= kPrefetchAllItems * 512u &&
-                    env_u32("TSAMD_PF", 0) != 0u;
   // first pass: exactly as many workgroups as are resident at once (one round; the kernel is
   // register-bound, so that is 2 per compute unit at K = 8 and 1 from K = 12 on)
   uint32_t first_target = 512;
@@ -385,26 +381,6 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
       first_target = (uint32_t)prop.multiProcessorCount * (uint32_t)std::min(nb, 4);
   }
   geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", first_target), p.chunk_first, c->grid_first);
-  // Uneven static split of the first pass (TSAMD_FIRST_SKEW="even1,odd1,even2,odd2", relative weights of a
-  // workgroup of the first / second dispatch round with an even / odd index; default: even split).
-  p.first_g1 = c->grid_first;
-  for (uint32_t &v : p.first_size) v = p.chunk_first;
-  {
-    const char *sk = getenv("TSAMD_FIRST_SKEW");
-    int cus = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, c->dev) == hipSuccess) cus = prop.multiProcessorCount;
-    double wgt[4];
-    if (sk && *sk && cus > 0 && c->grid_first > (uint32_t)cus &&
-        sscanf(sk, "%lf,%lf,%lf,%lf", &wgt[0], &wgt[1], &wgt[2], &wgt[3]) == 4 && wgt[0] > 0 && wgt[1] > 0 && wgt[2] > 0 &&
-        wgt[3] > 0) {
-      const uint32_t g1 = (uint32_t)cus, g2 = c->grid_first - g1, nitems = p.npad / c->first_vec;
-      const double units = ((g1 + 1) / 2) * wgt[0] + (g1 / 2) * wgt[1] + ((g2 + 1) / 2) * wgt[2] + (g2 / 2) * wgt[3];
-      p.first_g1 = g1;
-      for (int q = 0; q < 4; ++q)
-        p.first_size[q] = std::max<uint32_t>(64u, (uint32_t)std::ceil(wgt[q] * nitems / units / 64.0) * 64u);
-    }
-  }
 }
 
 // Switch the kernel sequence to the exchange buffer (rows + epoch flags pushed by every

@@ -17,13 +17,6 @@ void TSAMD_CAT(launch_k, TSAMD_K)(int which, uint32_t grid, uint32_t block, hipS
   constexpr int K = TSAMD_K;
   switch (which) {
     case kLaunchPass:
-      if constexpr (K <= kPrefetchAllMaxK) {
-        if (block == (512u | kLaunchPrefetchAll)) {  // every item's rows requested up-front (at most 4 items per thread)
-          hipLaunchKernelGGL((ts_pass<K, false, 512, 2, 4>), dim3(grid), dim3(512), 0, stream, p, par, nrows_hint);
-          break;
-        }
-      }
-      block &= ~kLaunchPrefetchAll;
       if (block == 1024)
         hipLaunchKernelGGL((ts_pass<K, false, 1024, 2>), dim3(grid), dim3(1024), 0, stream, p, par, nrows_hint);
       else if (block == 512)

@@ -285,7 +285,7 @@ __device__ __forceinline__ double row_partial_sum_xchg(const double *rows, uint3
 // src/snpsamplinge.cc:721-740).  The population with the largest a gets exp(0), so w never
 // underflows for all k at once.
 template <int KT>
-__device__ __forceinline__ void gamma_to_w(const double (&g)[KT], double (&w)[KT], const double *exp_tab = nullptr) {
+__device__ __forceinline__ void gamma_to_w(const double (&g)[KT], double (&w)[KT]) {
   double z[KT], a[KT];
   double amax = -1.0e300;
 #pragma unroll
@@ -294,7 +294,7 @@ __device__ __forceinline__ void gamma_to_w(const double (&g)[KT], double (&w)[KT
     amax = fmax(amax, a[k]);
   }
 #pragma unroll
-  for (int k = 0; k < KT; ++k) w[k] = z[k] * (exp_tab ? exp_nonpos_tab(a[k] - amax, exp_tab) : exp_nonpos(a[k] - amax));
+  for (int k = 0; k < KT; ++k) w[k] = z[k] * exp_nonpos(a[k] - amax);
 }
 
 // SVI step for one individual (update_gamma + update_rho_indiv,
@@ -351,9 +351,8 @@ struct Lanes<2> {
 #ifndef TSAMD_FIRST_WAVES
 #define TSAMD_FIRST_WAVES 1
 #endif
-template <int KT, bool FIRST, int BLOCK, int VEC, int PFD = 1>
+template <int KT, bool FIRST, int BLOCK, int VEC>
 __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1) void ts_pass(DevParams p, uint32_t par_arg, uint32_t nrows_hint) {
-  static_assert(PFD == 1 || (!FIRST && VEC == 2), "prefetch-all is a plain-pass variant");
   // par_arg: bit 0 = launch parity (state / partial-row slot written), bit 1 = plain pass sweeps
   // its chunk backwards (set for the odd passes of a SNP, a property of the pass, not of the
   // launch parity: any cut of a schedule into calls or graphs gives the same summation order)
@@ -372,10 +371,6 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   __shared__ double s_diff[J];
   __shared__ double s_red[kWaves][J];
   __shared__ double s_fin[BLOCK];
-#ifdef TSAMD_EXP_TAB
-  __shared__ double s_exp2[FIRST ? 64 : 1];
-  if (FIRST && threadIdx.x < 64) s_exp2[threadIdx.x] = kExp2Tab[threadIdx.x];  // (a barrier follows before its first use)
-#endif
 
   Ctl *ctl = p.ctl;
   const State *S = &ctl->st[par ^ 1u];
@@ -393,14 +388,8 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   const uint32_t tid = threadIdx.x;
   const size_t np = p.npad;
   const uint32_t nitems = p.npad / VEC;
-  uint32_t chunk = p.chunk, begin = blockIdx.x * p.chunk;
-  if constexpr (FIRST) {  // (uneven static split by dispatch round and workgroup parity, tsamd_device.h)
-    const uint32_t g1 = p.first_g1, r2 = blockIdx.x >= g1 ? 1u : 0u;
-    const uint32_t bb = r2 ? blockIdx.x - g1 : blockIdx.x;
-    const uint32_t base = r2 ? ((g1 + 1u) / 2u) * p.first_size[0] + (g1 / 2u) * p.first_size[1] : 0u;
-    begin = base + ((bb + 1u) / 2u) * p.first_size[2 * r2] + (bb / 2u) * p.first_size[2 * r2 + 1];
-    chunk = p.first_size[2 * r2 + (bb & 1u)];
-  }
+  const uint32_t chunk = FIRST ? p.chunk_first : p.chunk;
+  const uint32_t begin = blockIdx.x * chunk;
   const uint32_t end = min(begin + chunk, nitems);
 
   auto load_rows = [&](uint32_t i, WT (&wv)[KT]) {
@@ -431,17 +420,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   // array's last item): a load inside a branch would make every later wait conservative.
   const PendingIn pin = load_pending(S, J);
   auto item_or_last = [&](uint32_t t) { return cnt ? item(min(t, cnt - 1u)) : min(i0, nitems - 1u); };
-  // PFD > 1 (plain pass, at most PFD items per thread: N <= 1M at K <= 8): EVERY item's rows are
-  // requested before the state arrives -- the whole sweep's traffic overlaps the state wait and the
-  // epilogue, after which only arithmetic is left.
-  WT pf[PFD > 1 ? PFD - 1 : 1][KT];
-  if constexpr (!FIRST) {
-    load_rows(item_or_last(0), bufA);
-    if constexpr (PFD > 1) {
-#pragma unroll
-      for (int d = 1; d < PFD; ++d) load_rows(item_or_last((uint32_t)d), pf[d - 1]);
-    }
-  }
+  if constexpr (!FIRST) load_rows(item_or_last(0), bufA);
   __builtin_amdgcn_sched_barrier(0);
 
   const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
@@ -464,32 +443,8 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   // plain pass: the location is known as soon as the state is (it only changes in a first
   // pass), so the first column word is requested now and arrives during the epilogue
   uint32_t word_early = 0;
-  // PFD > 1: the column bits of a wave's item are 32 contiguous bytes (64 lanes x 2 individuals x 2
-  // bits): ONE scalar load per wave and item -- it does not queue behind the vector loads above
-  // (separate counter); each lane then picks its word.  (TSAMD_PF_VWORD: per-lane vector loads.)
-#ifdef TSAMD_PF_VWORD
-  constexpr int kPfWords = 1;
-#else
-  constexpr int kPfWords = 8;
-#endif
-  uint32_t pfw[PFD][kPfWords];
-  if constexpr (!FIRST) {
-    const uint32_t *colS = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride);
-    if constexpr (PFD > 1) {
-#pragma unroll
-      for (int d = 0; d < PFD; ++d) {
-#ifdef TSAMD_PF_VWORD
-        pfw[d][0] = colS[item_or_last((uint32_t)d) / kItemsPerWord];
-#else
-        const uint32_t w0 = __builtin_amdgcn_readfirstlane(item_or_last((uint32_t)d) / kItemsPerWord);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pfw[d][q] = colS[w0 + q];
-#endif
-      }
-    } else {
-      word_early = colS[item_or_last(0) / kItemsPerWord];
-    }
-  }
+  if constexpr (!FIRST)
+    word_early = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride)[item_or_last(0) / kItemsPerWord];
   __builtin_amdgcn_sched_barrier(0);
   const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                         : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
@@ -655,25 +610,6 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     };
     WT bufB[KT];
     uint32_t wordA = 0, wordB = 0;
-    if constexpr (PFD > 1) {
-      if (cnt) {
-#ifdef TSAMD_PF_VWORD
-        auto pick = [&](const uint32_t (&sw)[1]) { return sw[0]; };
-#else
-        const uint32_t lw = (tid >> 3) & 7u;  // this lane's word among the wave's eight
-        auto pick = [&](const uint32_t (&sw)[8]) {
-          const uint32_t a = (lw & 1u) ? sw[1] : sw[0], b = (lw & 1u) ? sw[3] : sw[2];
-          const uint32_t c = (lw & 1u) ? sw[5] : sw[4], e = (lw & 1u) ? sw[7] : sw[6];
-          const uint32_t ab = (lw & 2u) ? b : a, ce = (lw & 2u) ? e : c;
-          return (lw & 4u) ? ce : ab;
-        };
-#endif
-        consume(item(0), bufA, pick(pfw[0]));
-#pragma unroll
-        for (int d = 1; d < PFD; ++d)
-          if ((uint32_t)d < cnt) consume(item((uint32_t)d), pf[d - 1], pick(pfw[d]));
-      }
-    } else
     if (cnt) {
       wordA = word_early;
       uint32_t t = 0;
@@ -723,22 +659,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
     CT cv{}, cv_n{};
     uint32_t word = 0, pword = 0, word_n = 0, pword_n = 0;
     if (i0 < end) load_item(i0, wv, gv, cv, word, pword);
-#ifdef TSAMD_PRIO_FLIP
-    // two workgroups share a compute unit and the hardware favours the older one, which then
-    // finishes early and leaves the younger alone at one wave per SIMD: the younger half of the
-    // grid gets priority for the first half of its items, the older half for its second half
-    const bool younger = blockIdx.x >= (gridDim.x >> 1);
-    uint32_t it2 = 0;
-    const uint32_t cnt_u = __builtin_amdgcn_readfirstlane(cnt);
-#endif
     for (uint32_t i = i0; i < end; i += BLOCK) {
-#ifdef TSAMD_PRIO_FLIP
-      if ((it2 < cnt_u) == younger)
-        __builtin_amdgcn_s_setprio(1);
-      else
-        __builtin_amdgcn_s_setprio(0);
-      it2 += 2u;
-#endif
       const uint32_t inext = (i + BLOCK < end) ? i + BLOCK : i;  // clamped: static load counts
       load_item(inext, wv_n, gv_n, cv_n, word_n, pword_n);
       __builtin_amdgcn_sched_barrier(0);
@@ -760,11 +681,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
             gamma_step_one<KT>(g[v], w[v], sb0, sb1, mom, dad, cn[v], p);
 #endif
 #if !defined(TSAMD_ABL) || TSAMD_ABL == 3
-#ifdef TSAMD_EXP_TAB
-            gamma_to_w<KT>(g[v], w[v], s_exp2);
-#else
             gamma_to_w<KT>(g[v], w[v]);
-#endif
 #endif
           }
         }
@@ -985,9 +902,6 @@ __global__ __launch_bounds__(kBlock) void ts_refresh_w(DevParams p) {
 // Host-side launcher of the K-specialised kernels; one translation unit per K
 // (tsamd_inst.hip compiled with -DTSAMD_K=<k>) defines tsamd::launch_k<k>.
 enum LaunchWhich { kLaunchPass = 0, kLaunchFirst = 1, kLaunchRefresh = 2 };
-constexpr uint32_t kLaunchPrefetchAll = 0x10000u;  // flag in the block argument: ts_pass<K, false, 512, 2, 4>
-constexpr int kPrefetchAllMaxK = 8;                // (its 4 x K x 16-byte row buffers fit two waves per SIMD up to here)
-constexpr uint32_t kPrefetchAllItems = 4;
 using LaunchFn = void (*)(int which, uint32_t grid, uint32_t block, hipStream_t stream, const DevParams &p,
                           uint32_t par, uint32_t nrows_hint);
 
