@@ -16,5 +16,5 @@ for pat in sys.argv[1:]:
             continue
         q = (f"select {name_col}, {ctr_col}, count(*), avg({val_col}), min({val_col}), max({val_col}) "
              f"from pmc_events group by {name_col}, {ctr_col} order by sum({val_col}) desc")
-        for name, ctr, n, avg, mn, mx in db.execute(q).fetchall()[:12]:
-            print(f"{str(name)[:64]:64s} {ctr:14s} n={n:6d} avg={avg:14.2f} min={mn:14.2f} max={mx:14.2f}")
+        for name, ctr, n, avg, mn, mx in db.execute(q).fetchall()[:48]:
+            print(f"{str(name)[:64]:64s} {ctr:22s} n={n:6d} avg={avg:14.2f} min={mn:14.2f} max={mx:14.2f}")
