@@ -145,6 +145,7 @@ struct Run {
   std::vector<std::string> labels;      // -idfile: individual labels, echoed into gammasave.txt
   std::vector<uint8_t> text_payload;   // .012 input: the columns re-packed as PLINK codes, kept for read_column
   uint64_t bytes_per_snp = 0;
+  bool columns_on_device = false;       // individual-major input: a column exists only in HBM (read_column downloads it)
 
   std::string file_str(const std::string &f) const { return prefix + f; }
   uint32_t duration() const { return (uint32_t)(time(nullptr) - start_time); }
@@ -336,8 +337,35 @@ void read_bed(Run &r) {
     exit(-1);
   }
   if (magic[2] == 0) {
-    fprintf(stderr, "individual major mode not supported yet!\n");
-    exit(-1);
+    // PLINK individual-major layout: refused by the reference (src/snp.cc:176-178); here the rows are
+    // transposed on the device into the SNP-major columns the engine keeps (tsamd_upload_bed_indiv_major)
+    printf("+ individual-major .bed: transposing on the device\n");
+    const uint64_t bpi = ((uint64_t)o.l + 3) / 4;
+    const uint32_t per = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(o.n, ((uint64_t)256 << 20) / bpi / 16 * 16));
+    std::vector<uint8_t> rows((size_t)per * bpi);
+    for (uint32_t i0 = 0; i0 < o.n; i0 += per) {
+      const uint32_t ni = std::min(per, o.n - i0);
+      if (fread(rows.data(), bpi, ni, f) != ni) {
+        fprintf(stderr, "%s is truncated: fewer than %u individuals\n", r.bed_path.c_str(), o.n);
+        exit(-1);
+      }
+      for (tsamd_ctx *c : r.ctxs) TS(r, tsamd_upload_bed_indiv_major(c, rows.data(), bpi, i0, ni));
+      printf("\r%d individuals read", i0 + ni);
+      fflush(stdout);
+    }
+    fclose(f);
+    r.columns_on_device = true;
+    uint64_t cnt[4] = {0, 0, 0, 0};
+    for (tsamd_ctx *c : r.ctxs) {
+      uint64_t part[4];
+      TS(r, tsamd_genotype_counts(c, 0, o.l, part));
+      for (int q = 0; q < 4; ++q) cnt[q] += part[q];
+    }
+    r.plog_u("missing snps", cnt[1]);
+    r.plog_u("0s snps", cnt[3]);
+    r.plog_u("1s snps", cnt[2]);
+    r.plog_u("2s snps", cnt[0]);
+    return;
   } else if (magic[2] != 1) {
     fprintf(stderr, "mode problem in %s\n", r.bed_path.c_str());
     exit(-1);
@@ -501,6 +529,15 @@ void read_012(Run &r) {
 }
 
 std::vector<uint8_t> read_column(Run &r, uint32_t loc) {
+  if (r.columns_on_device) {  // shard after shard (shards start on multiples of 4 individuals: whole bytes)
+    std::vector<uint8_t> col(r.bytes_per_snp);
+    for (size_t i = 0; i < r.ctxs.size(); ++i) {
+      uint32_t b, c;
+      shard_span(r, i, b, c);
+      TS(r, tsamd_download_bed(r.ctxs[i], loc, col.data() + b / 4, ((uint64_t)c + 3) / 4));
+    }
+    return col;
+  }
   if (!r.text_payload.empty())
     return std::vector<uint8_t>(r.text_payload.begin() + (size_t)loc * r.bytes_per_snp,
                                 r.text_payload.begin() + (size_t)(loc + 1) * r.bytes_per_snp);

@@ -96,6 +96,15 @@ int tsamd_host_alloc(void **ptr, uint64_t bytes);
 void tsamd_host_free(void *ptr);
 int tsamd_upload_bed_async(tsamd_ctx *ctx, const uint8_t *payload, uint64_t bytes_per_snp,
                            uint32_t first_loc, uint32_t n_locs);
+/* PLINK's other .bed layout, individual-major (third magic byte 0), which the reference refuses
+ * ("individual major mode not supported yet!", src/snp.cc:176-178): n_indivs rows of
+ * bytes_per_indiv = ceil(l/4) bytes, row r = GLOBAL individual first_indiv + r, location j at bits
+ * 2(j%4) of byte j/4, same 2-bit codes.  The rows are transposed on the device into the SNP-major
+ * columns the engine keeps.  first_indiv must be a multiple of 16; a batch may be any number of
+ * rows (the last word's missing individuals stay "missing" until a later batch brings them, so
+ * upload in ascending order).  A context takes the rows of its own shard.  Drops all held-out folds. */
+int tsamd_upload_bed_indiv_major(tsamd_ctx *ctx, const uint8_t *payload, uint64_t bytes_per_indiv,
+                                 uint32_t first_indiv, uint32_t n_indivs);
 /* replaces the genotype tallies of SNP::read_bed (src/snp.cc:203-216, reported in param.txt,
  * :245-247): counts[c] = entries with PLINK code c (00, 01 = missing, 10, 11) among the shard's
  * individuals in columns [first_loc, first_loc + n_locs), counted on the device.  Held-out

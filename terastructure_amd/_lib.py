@@ -42,6 +42,7 @@ SYMBOLS = {
     "tsamd_last_error": (C.c_char_p, [_vp]),
     "tsamd_upload_bed": (_int, [_vp, _vp, _u64, _u32, _u32]),
     "tsamd_upload_bed_async": (_int, [_vp, _vp, _u64, _u32, _u32]),
+    "tsamd_upload_bed_indiv_major": (_int, [_vp, _vp, _u64, _u32, _u32]),
     "tsamd_host_alloc": (_int, [C.POINTER(_vp), _u64]),
     "tsamd_host_free": (None, [_vp]),
     "tsamd_genotype_counts": (_int, [_vp, _u32, _u32, _pu64]),

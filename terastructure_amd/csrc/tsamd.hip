@@ -701,6 +701,51 @@ int tsamd_upload_bed_async(tsamd_ctx *c, const uint8_t *payload, uint64_t bytes_
   return upload_bed_impl(c, payload, bytes_per_snp, first_loc, n_locs, false);
 }
 
+int tsamd_upload_bed_indiv_major(tsamd_ctx *c, const uint8_t *payload, uint64_t bytes_per_indiv, uint32_t first_indiv,
+                                 uint32_t n_indivs) {
+  CHECK_CTX(c);
+  if (!payload) return fail(c, TSAMD_EINVAL, "null payload");
+  if (bytes_per_indiv != ((uint64_t)c->cfg.l + 3) / 4)
+    return fail(c, TSAMD_EINVAL, "bytes_per_indiv %llu != ceil(l/4) = %llu", (unsigned long long)bytes_per_indiv,
+                (unsigned long long)(((uint64_t)c->cfg.l + 3) / 4));
+  if ((uint64_t)first_indiv + n_indivs > c->cfg.n)
+    return fail(c, TSAMD_EINVAL, "individuals [%u, %u) exceed n = %u", first_indiv, first_indiv + n_indivs, c->cfg.n);
+  if (first_indiv % 16u != 0u) return fail(c, TSAMD_EINVAL, "first_indiv must be a multiple of 16 (whole column words)");
+  // this shard's part of the batch
+  const uint64_t lo = std::max<uint64_t>(first_indiv, c->n_begin), hi = std::min<uint64_t>((uint64_t)first_indiv + n_indivs,
+                                                                                           (uint64_t)c->n_begin + c->n_local);
+  if (lo >= hi) return TSAMD_OK;
+  if ((lo - c->n_begin) % 16u != 0u)
+    return fail(c, TSAMD_EUNSUPPORTED, "individual-major upload needs shard boundaries on multiples of 16 individuals");
+  HIP_TRY(c, hipSetDevice(c->dev));
+  const uint32_t rows_total = (uint32_t)(hi - lo), first_local = (uint32_t)(lo - c->n_begin);
+  const size_t budget = (size_t)256u << 20;  // device staging: at most 256 MB of rows at a time
+  const uint32_t per = (uint32_t)std::max<size_t>(kTrRows, std::min<size_t>(rows_total, budget / bytes_per_indiv / kTrRows * kTrRows));
+  uint8_t *d_rows = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&d_rows, (size_t)per * bytes_per_indiv));
+  hipError_t e = hipSuccess;
+  for (uint32_t r0 = 0; r0 < rows_total && e == hipSuccess; r0 += per) {
+    const uint32_t nr = std::min(per, rows_total - r0);
+    e = hipMemcpyAsync(d_rows, payload + (size_t)(lo - first_indiv + r0) * bytes_per_indiv, (size_t)nr * bytes_per_indiv,
+                       hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) break;
+    const uint32_t nbytes = (uint32_t)bytes_per_indiv;
+    for (uint32_t q0 = 0; q0 < nbytes; q0 += 65535u * kTrBytes) {  // (grid.y limit)
+      const uint32_t nq = std::min<uint32_t>(nbytes - q0, 65535u * kTrBytes);
+      const uint32_t locs0 = 4u * q0, nl = std::min<uint32_t>(c->cfg.l - locs0, 4u * nq);
+      hipLaunchKernelGGL(ts_transpose_indiv_major, dim3((nr + kTrRows - 1) / kTrRows, (nq + kTrBytes - 1) / kTrBytes), dim3(256), 0,
+                         c->stream, d_rows + q0, (uint64_t)bytes_per_indiv, nr, first_local + r0, locs0, nl, c->p.bed,
+                         (uint64_t)c->p.colstride);
+    }
+    e = hipStreamSynchronize(c->stream);  // the staging buffer is reused
+  }
+  hipFree(d_rows);
+  if (e != hipSuccess) return fail(c, TSAMD_EHIP, "upload_bed_indiv_major: %s", hipGetErrorString(e));
+  c->held.clear();  // every column changed: validation folds are dropped
+  c->held_dirty = true;
+  return TSAMD_OK;
+}
+
 int tsamd_host_alloc(void **ptr, uint64_t bytes) {
   if (!ptr) return fail(nullptr, TSAMD_EINVAL, "null pointer");
   *ptr = nullptr;
@@ -961,14 +1006,25 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   if (use_graph) {
     const uint32_t per_snp = kernels_per_snp(c);
     uint32_t left = n;
-    for (int level = (int)kGraphLevels - 1; level >= 0; --level) {
-      const uint32_t snps = 1u << level;
-      while (left >= snps) {
-        HIP_TRY(c, hipGraphLaunch(c->graphs[level][c->q & 1u].exec, c->stream));
-        c->q += (uint64_t)snps * per_snp;
-        left -= snps;
-      }
-    }
+    auto replay = [&](uint32_t level) -> int {
+      HIP_TRY(c, hipGraphLaunch(c->graphs[level][c->q & 1u].exec, c->stream));
+      c->q += (uint64_t)(1u << level) * per_snp;
+      left -= 1u << level;
+      return TSAMD_OK;
+    };
+    // Ramp-up: submitting a 16-SNP graph (160 kernel nodes) costs the host ~90 us, during which an
+    // idle device would wait; so the first graphs are small ones (1, 1, 2, 4, 8 SNPs): the device
+    // starts after the first, cheap submission and every later one is hidden behind work already
+    // queued.  (Any order of graphs gives the same bits.)
+    static const uint32_t ramp[] = {0, 0, 1, 2, 3};
+    for (uint32_t level : ramp)
+      if (left >= (1u << level))
+        if (int rc = replay(level)) return rc;
+    while (left >= kGraphSnps)
+      if (int rc = replay(kGraphLevels - 1)) return rc;
+    for (int level = (int)kGraphLevels - 2; level >= 0; --level)
+      if (left >= (1u << level))
+        if (int rc = replay((uint32_t)level)) return rc;
     c->prev_rows = c->cfg.max_inner > 1 ? c->grid : c->grid_first;
   } else {
     for (uint32_t i = 0; i < n; ++i)

@@ -54,6 +54,53 @@ __global__ void ts_fix_tail(uint8_t *bed, uint64_t colstride, uint32_t first_loc
   *b = (uint8_t)((*b & keep_mask) | (0x55u & ~keep_mask));
 }
 
+// PLINK individual-major payload -> the SNP-major 2-bit columns the engine keeps (a 2-bit matrix
+// transpose).  rows: [n_rows][row_bytes] staged on the device, row r = individual (first local id +
+// r), location j at bits 2(j%4) of byte j/4.  One workgroup transposes a tile of kTrRows
+// individuals x 4*kTrBytes locations through LDS: coalesced row reads in, one 32-bit word (16
+// individuals of one location) per store out, 64 contiguous bytes per location and tile.
+// first_local must be a multiple of 16 (whole output words); rows past n_rows read as missing.
+constexpr int kTrRows = 256;   // individuals per tile
+constexpr int kTrBytes = 64;   // input bytes per row and tile (256 locations)
+__global__ __launch_bounds__(256) void ts_transpose_indiv_major(const uint8_t *rows, uint64_t row_bytes, uint32_t n_rows,
+                                                                uint32_t first_local, uint32_t first_loc, uint32_t n_locs,
+                                                                uint8_t *bed, uint64_t colstride) {
+  __shared__ uint8_t tile[kTrRows][kTrBytes + 4];  // (+4: row stride 68 bytes spreads the column reads over the banks)
+  const uint32_t r0 = blockIdx.x * kTrRows, q0 = blockIdx.y * kTrBytes;
+  const uint32_t nbytes = (n_locs + 3u) / 4u;  // payload bytes per row that carry locations [first_loc, first_loc + n_locs)
+  for (uint32_t e = threadIdx.x; e < kTrRows * kTrBytes; e += 256u) {
+    const uint32_t r = e / kTrBytes, q = e % kTrBytes;
+    uint8_t v = 0x55;  // missing
+    if (r0 + r < n_rows && q0 + q < nbytes) v = rows[(size_t)(r0 + r) * row_bytes + q0 + q];
+    tile[r][q] = v;
+  }
+  __syncthreads();
+  // thread -> (input byte position q, group of 64 individuals g): 4 locations x 4 output words
+  const uint32_t q = threadIdx.x % kTrBytes, g = threadIdx.x / kTrBytes;  // g in 0..3
+  uint32_t out[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) out[j][wd] = 0u;
+#pragma unroll
+  for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t b = tile[g * 64u + wd * 16u + i][q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[j][wd] |= ((b >> (2 * j)) & 3u) << (2 * i);
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t l = 4u * (q0 + q) + j;
+    if (l >= n_locs) continue;
+    uint32_t *col = reinterpret_cast<uint32_t *>(bed + (size_t)(first_loc + l) * colstride) + (first_local + r0 + g * 64u) / 16u;
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd)
+      if (r0 + g * 64u + wd * 16u < n_rows) col[wd] = out[j][wd];  // (a word's individuals past n_rows are written as missing)
+  }
+}
+
 // counts of the four PLINK codes over the shard's real individuals in columns [first_loc, +n_locs)
 // (SNP::read_bed's tallies for param.txt, src/snp.cc:203-216, :245-247); one workgroup per column
 // slice, 64-bit words, three popcounts per word; out[4] accumulated with atomics.

@@ -96,6 +96,14 @@ class Engine:
         """payload at address ptr in pinned memory (host_alloc); valid until the next synchronize()"""
         self._check(self.h.tsamd_upload_bed_async(self.ctx, ptr, bytes_per_snp, first_loc, n_locs))
 
+    def upload_bed_indiv_major(self, payload, first_indiv=0):
+        """payload: uint8 [n_indivs][ceil(l/4)] PLINK individual-major rows (global individuals from first_indiv)"""
+        payload = np.ascontiguousarray(payload, dtype=np.uint8)
+        if payload.ndim != 2:
+            raise ValueError("payload must be [n_indivs][bytes_per_indiv]")
+        self._check(self.h.tsamd_upload_bed_indiv_major(self.ctx, payload.ctypes.data, payload.shape[1], first_indiv,
+                                                        payload.shape[0]))
+
     def genotype_counts(self, first_loc=0, n_locs=None):
         """counts of the PLINK codes (00, 01 = missing, 10, 11) over the shard's individuals"""
         n_locs = self.l - first_loc if n_locs is None else n_locs

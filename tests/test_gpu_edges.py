@@ -136,3 +136,29 @@ def test_schedule_of_every_location_in_order(ts):
         for loc in range(l):
             orc.snp_update(loc)
         assert_state_close(eng, orc, 1e-9, "in order")
+
+
+@pytest.mark.parametrize("n,l", [(1003, 517), (4096, 64), (70, 5000)])
+def test_individual_major_upload_equals_snp_major(ts, n, l):
+    """PLINK's individual-major layout (third magic byte 0; the reference refuses it, src/snp.cc:176-178)
+    transposed on the device gives the same 2-bit columns as the SNP-major upload, for sizes that are not
+    multiples of the transpose tile, in several batches; the device-side genotype tallies agree with numpy."""
+    k = 3
+    y, _, _ = psd_genotypes(n, l, k, 17 + n, 0.07)
+    cols = pack_bed(y)          # [l][ceil(n/4)]  SNP-major
+    rows = pack_bed(y.T.copy())  # [n][ceil(l/4)]  individual-major: location j at bits 2(j%4) of byte j/4
+    with ts.Engine(n, l, k) as a, ts.Engine(n, l, k) as b:
+        a.upload_bed(cols)
+        cut = min(n, 48) // 16 * 16 or n   # first batch: a multiple of 16 individuals
+        b.upload_bed_indiv_major(rows[:cut], 0)
+        if cut < n:
+            mid = cut + (n - cut) // 2 // 16 * 16
+            b.upload_bed_indiv_major(rows[cut:mid], cut)
+            b.upload_bed_indiv_major(rows[mid:], mid)
+        for loc in range(l):
+            assert np.array_equal(a.download_bed(loc), b.download_bed(loc)), loc
+        want = np.array([(y == 0).sum(), (y == 3).sum(), (y == 1).sum(), (y == 2).sum()], dtype=np.uint64)  # codes 00 01 10 11
+        assert np.array_equal(a.genotype_counts(), want) and np.array_equal(b.genotype_counts(), want)
+        assert np.array_equal(a.genotype_counts(3, 2), np.array([(y[3:5] == v).sum() for v in (0, 3, 1, 2)], dtype=np.uint64))
+        with pytest.raises(ts.TsamdError):
+            b.upload_bed_indiv_major(rows[:8], 8)      # batches start on multiples of 16 individuals

@@ -272,3 +272,38 @@ def test_streaming_ingest_rate(host_bin, tmp_path):
     assert cnt("missing snps") == want[1] and cnt("0s snps") == want[3]      # (labels swapped like the reference)
     assert cnt("1s snps") == want[2] and cnt("2s snps") == want[0]
     assert gbps > 4.0, line
+
+
+@pytest.mark.gpu
+def test_individual_major_bed_equals_snp_major(host_bin, tmp_path):
+    """A PLINK individual-major .bed (magic 6c 1b 00), which the reference refuses, gives byte-identical
+    outputs to the SNP-major file of the same genotypes (transposed on the device at ingest; the
+    validation sample then reads its columns back from HBM)."""
+    from helpers import pack_bed, unpack_bed
+
+    data = tmp_path / "data"
+    data.mkdir()
+    for f in ("test.bed", "test.bim", "test.fam"):
+        shutil.copy(os.path.join(REF_DATA, f), data / f)
+    raw = np.fromfile(data / "test.bed", dtype=np.uint8)[3:].reshape(10000, 50)
+    y = unpack_bed(raw, 200)                                   # [l][n]
+    with open(data / "im.bed", "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x00]))
+        f.write(pack_bed(y.T.copy()).tobytes())               # [n][ceil(l/4)]
+    for ext in (".bim", ".fam"):
+        shutil.copy(data / ("test" + ext), data / ("im" + ext))
+    outs = {}
+    for name in ("test.bed", "im.bed"):
+        cmd = [host_bin, "-file", name, "-n", "200", "-l", "10000", "-k", "3", "-stochastic", "-nthreads", "1",
+               "-rfreq", "1000", "-seed", "99", "-label", name[:2], "-max-iter", "2100"]
+        r = subprocess.run(cmd, cwd=data, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+        run = data / f"n200-k3-l10000-{name[:2]}-seed99"
+        outs[name] = {f: open(run / f).read() for f in ("theta.txt", "gamma.txt", "validation.txt", "param.txt")}
+    a, b = outs["test.bed"], outs["im.bed"]
+    assert a["theta.txt"] == b["theta.txt"] and a["gamma.txt"] == b["gamma.txt"]
+    assert [ln.split("\t")[0::2] for ln in a["validation.txt"].splitlines()] == \
+           [ln.split("\t")[0::2] for ln in b["validation.txt"].splitlines()]
+    keys = ("missing snps", "0s snps", "1s snps", "2s snps", "total validation snps")
+    pick = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(keys)]  # noqa: E731
+    assert pick(a["param.txt"]) == pick(b["param.txt"])
