@@ -1012,18 +1012,14 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
       left -= 1u << level;
       return TSAMD_OK;
     };
-    // Ramp-up: submitting a 16-SNP graph (160 kernel nodes) costs the host ~90 us, during which an
-    // idle device would wait; so the first graphs are small ones (1, 1, 2, 4, 8 SNPs): the device
-    // starts after the first, cheap submission and every later one is hidden behind work already
-    // queued.  (Any order of graphs gives the same bits.)
-    static const uint32_t ramp[] = {0, 0, 1, 2, 3};
-    for (uint32_t level : ramp)
-      if (left >= (1u << level))
-        if (int rc = replay(level)) return rc;
-    while (left >= kGraphSnps)
-      if (int rc = replay(kGraphLevels - 1)) return rc;
-    for (int level = (int)kGraphLevels - 2; level >= 0; --level)
-      if (left >= (1u << level))
+    // Submitting a 16-SNP graph (160 kernel nodes) costs the host ~90 us, during which an idle
+    // device would wait, and every graph boundary costs the device ~8 us: so the first graph is a
+    // small one (4 SNPs: the device starts after ~20 us and the larger submissions hide behind its
+    // work), the rest are as few graphs as possible.  (Any order of graphs gives the same bits.)
+    if (left > 4u)
+      if (int rc = replay(2)) return rc;
+    for (int level = (int)kGraphLevels - 1; level >= 0; --level)
+      while (left >= (1u << level))
         if (int rc = replay((uint32_t)level)) return rc;
     c->prev_rows = c->cfg.max_inner > 1 ? c->grid : c->grid_first;
   } else {
