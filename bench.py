@@ -338,10 +338,10 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pass_kernel_pmc.json")
             if os.path.exists(pmc):
                 try:
-                    rec = json.load(open(pmc))
-                    if rec.get("n") == n and rec.get("k") == k and rec.get("n_gpus") == world:
-                        traffic = rec.get("hbm_bytes_per_launch")
-                        first_traffic = rec.get("first_pass_hbm_bytes_per_launch")
+                    for rec in json.load(open(pmc)).get("records", []):
+                        if rec.get("n") == n and rec.get("k") == k and rec.get("n_gpus") == world:
+                            traffic = rec.get("hbm_bytes_per_launch")
+                            first_traffic = rec.get("first_pass_hbm_bytes_per_launch")
                 except Exception:  # noqa: BLE001
                     pass
             try:
