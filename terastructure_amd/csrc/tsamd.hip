@@ -185,7 +185,7 @@ uint32_t next_parity(tsamd_ctx *c) { return (uint32_t)(c->q++ & 1u); }
 int enqueue_pass(tsamd_ctx *c, uint32_t pass) {
   const bool first = pass == 0;
   const uint32_t par = next_parity(c);
-  const uint32_t par_arg = par | ((pass & 1u) << 1);
+  const uint32_t par_arg = par | ((c->p.sweep_alternate ? (pass & 1u) : 0u) << 1);
   // rows of the previous launch of the sequence: a first pass follows a plain pass (or a
   // kernel that left nothing pending), a plain pass follows the first pass or a plain pass
   const uint32_t hint = c->prev_rows;

@@ -7,6 +7,10 @@
 #error "compile with -DTSAMD_K=<populations>"
 #endif
 
+// leading scalar arguments of ts_pass (kernel-argument preload, tsamd_kernels.h), then the full parameter block
+#define TSAMD_PASS_ARGS(chunk) \
+  p.ctl, p.partials, p.w, p.npad, (chunk), par, nrows_hint, (p.xchg_world == 0u && p.rows_from_lt == 0u) ? 1u : 0u, p
+
 #define TSAMD_CAT2(a, b) a##b
 #define TSAMD_CAT(a, b) TSAMD_CAT2(a, b)
 
@@ -18,17 +22,17 @@ void TSAMD_CAT(launch_k, TSAMD_K)(int which, uint32_t grid, uint32_t block, hipS
   switch (which) {
     case kLaunchPass:
       if (block == 1024)
-        hipLaunchKernelGGL((ts_pass<K, false, 1024, 2>), dim3(grid), dim3(1024), 0, stream, p, par, nrows_hint);
+        hipLaunchKernelGGL((ts_pass<K, false, 1024, 2>), dim3(grid), dim3(1024), 0, stream, TSAMD_PASS_ARGS(p.chunk));
       else if (block == 512)
-        hipLaunchKernelGGL((ts_pass<K, false, 512, 2>), dim3(grid), dim3(512), 0, stream, p, par, nrows_hint);
+        hipLaunchKernelGGL((ts_pass<K, false, 512, 2>), dim3(grid), dim3(512), 0, stream, TSAMD_PASS_ARGS(p.chunk));
       else
-        hipLaunchKernelGGL((ts_pass<K, false, 256, 2>), dim3(grid), dim3(256), 0, stream, p, par, nrows_hint);
+        hipLaunchKernelGGL((ts_pass<K, false, 256, 2>), dim3(grid), dim3(256), 0, stream, TSAMD_PASS_ARGS(p.chunk));
       break;
     case kLaunchFirst:
       if (block == 1)  // TSAMD_FIRST_VEC=2: two individuals per thread
-        hipLaunchKernelGGL((ts_pass<K, true, 256, 2>), dim3(grid), dim3(256), 0, stream, p, par, nrows_hint);
+        hipLaunchKernelGGL((ts_pass<K, true, 256, 2>), dim3(grid), dim3(256), 0, stream, TSAMD_PASS_ARGS(p.chunk_first));
       else
-        hipLaunchKernelGGL((ts_pass<K, true, 256, 1>), dim3(grid), dim3(256), 0, stream, p, par, nrows_hint);
+        hipLaunchKernelGGL((ts_pass<K, true, 256, 1>), dim3(grid), dim3(256), 0, stream, TSAMD_PASS_ARGS(p.chunk_first));
       break;
     default:
       hipLaunchKernelGGL((ts_refresh_w<K>), dim3((p.npairs + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, p);

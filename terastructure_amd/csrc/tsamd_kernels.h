@@ -352,7 +352,12 @@ struct Lanes<2> {
 #define TSAMD_FIRST_WAVES 1
 #endif
 template <int KT, bool FIRST, int BLOCK, int VEC>
-__global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1) void ts_pass(DevParams p, uint32_t par_arg, uint32_t nrows_hint) {
+__global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1) void ts_pass(Ctl *ctl_a, double *partials_a, double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
+                                                                                           uint32_t nrows_hint, uint32_t local_rows_a, const DevParams p) {
+  // The leading scalar arguments repeat what the kernel needs before anything else (control block,
+  // partial rows, weight rows, geometry): built with -amdgpu-kernarg-preload-count they arrive in
+  // SGPRs with the wave, so the first loads do not wait for a kernel-argument fetch; the rest of
+  // the parameter block is fetched when it is first needed.
   // par_arg: bit 0 = launch parity (state / partial-row slot written), bit 1 = plain pass sweeps
   // its chunk backwards (set for the odd passes of a SNP, a property of the pass, not of the
   // launch parity: any cut of a schedule into calls or graphs gives the same summation order)
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   __shared__ double s_red[kWaves][J];
   __shared__ double s_fin[BLOCK];
 
-  Ctl *ctl = p.ctl;
+  Ctl *ctl = ctl_a;
   const State *S = &ctl->st[par ^ 1u];
   State *W = &ctl->st[par];
 #ifdef TSAMD_WGTIME
@@ -385,34 +390,40 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
 #else
 #define TSAMD_TR(k) do { } while (0)
 #endif
+  // The state of the sequence first (scalar loads: everything below that matters waits for them).
+  const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
+  const uint32_t siters = S->iters, snrows = S->nrows;
+  const uint32_t sched_len = ctl->sched_len;
+  const uint32_t *sched = ctl->sched;
+  __builtin_amdgcn_sched_barrier(0);
   const uint32_t tid = threadIdx.x;
-  const size_t np = p.npad;
-  const uint32_t nitems = p.npad / VEC;
-  const uint32_t chunk = FIRST ? p.chunk_first : p.chunk;
+  const size_t np = npad_a;
+  const uint32_t nitems = npad_a / VEC;
+  const uint32_t chunk = chunk_a;
   const uint32_t begin = blockIdx.x * chunk;
   const uint32_t end = min(begin + chunk, nitems);
 
   auto load_rows = [&](uint32_t i, WT (&wv)[KT]) {
 #pragma unroll
-    for (int k = 0; k < KT; ++k) wv[k] = reinterpret_cast<const WT *>(p.w + (size_t)k * np)[i];
+    for (int k = 0; k < KT; ++k) wv[k] = reinterpret_cast<const WT *>(w_a + (size_t)k * np)[i];
   };
 
   // Loads that do not depend on the state machine go first, so that they overlap its
   // dependent loads.  Order matters (loads return in order): the previous launch's partial
   // rows -- needed by the prologue; single GPU only; nrows_hint is that launch's grid size, a
   // launch-time constant -- then the first item's row data.
-  const bool local_rows = p.xchg_world == 0u && p.rows_from_lt == 0u;
+  const bool local_rows = local_rows_a != 0u;  // = p.xchg_world == 0 && p.rows_from_lt == 0
   RowSum<BLOCK> rowsum;
   // (first pass: only workgroup 0 needs the previous SNP's rows unless the slow path is taken)
   const bool rows_issued = local_rows && (!FIRST || blockIdx.x == 0);
-  rowsum.issue(p.partials + (size_t)(par ^ 1u) * kMaxGrid * (2 * KT), rows_issued ? nrows_hint : 0u, 2 * KT);
+  rowsum.issue(partials_a + (size_t)(par ^ 1u) * kMaxGrid * (2 * KT), rows_issued ? nrows_hint : 0u, 2 * KT);
   // Plain passes sweep their chunk forwards and backwards alternately (passes 2, 4, ... of a
   // SNP backwards): a pass starts on the addresses the previous one touched last (measured
   // 13.1 -> 11.1 us at N = 1M, K = 8; TSAMD_SWEEP=0 disables).
   WT bufA[KT];
   const uint32_t i0 = begin + tid;
   const uint32_t cnt = (i0 < end) ? (end - i0 + BLOCK - 1u) / BLOCK : 0u;  // this thread's items
-  const bool rev = !FIRST && (par_arg & 2u) != 0u && p.sweep_alternate != 0u;
+  const bool rev = !FIRST && (par_arg & 2u) != 0u;  // (the host sets the bit only when alternating sweeps are on)
   auto item = [&](uint32_t t) { return rev ? i0 + (cnt - 1u - t) * BLOCK : i0 + t * BLOCK; };
   // What the epilogue needs (partial rows above, its per-thread inputs here) is requested before
   // the sweep's own data: loads return in order.  The sweep loads below are issued
@@ -422,11 +433,6 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   auto item_or_last = [&](uint32_t t) { return cnt ? item(min(t, cnt - 1u)) : min(i0, nitems - 1u); };
   if constexpr (!FIRST) load_rows(item_or_last(0), bufA);
   __builtin_amdgcn_sched_barrier(0);
-
-  const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
-  const uint32_t siters = S->iters, snrows = S->nrows;
-  const uint32_t sched_len = ctl->sched_len;
-  const uint32_t *sched = ctl->sched;
   // first pass: what it needs about the new SNP was captured one SNP ahead (NextSnp); both slots
   // are requested with the state, the one whose for_idx matches is used
   uint32_t nx_for[2] = {0xffffffffu, 0xffffffffu}, nx_ent[2] = {0u, 0u};
@@ -448,9 +454,9 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
   __builtin_amdgcn_sched_barrier(0);
   const double *rowsR = p.xchg_world  ? p.xchg->rows[par ^ 1u]
                         : p.rows_from_lt ? ctl->lt_sum[par ^ 1u]
-                                         : p.partials + (size_t)(par ^ 1u) * kMaxGrid * J;
+                                         : partials_a + (size_t)(par ^ 1u) * kMaxGrid * J;
   const uint32_t nrowsR = p.xchg_world ? p.xchg_world * snrows : p.rows_from_lt ? 1u : snrows;
-  double *rowsW = p.partials + (size_t)par * kMaxGrid * J;
+  double *rowsW = partials_a + (size_t)par * kMaxGrid * J;
 
 #ifdef TSAMD_TRACE
   if (sidx == 12345678u) return;  // (forces the state load to complete before the stamp)
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
             tw[v] = w[v][k];
           }
           reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = LN::pack(tg);
-          reinterpret_cast<WT *>(p.w + (size_t)k * np)[i] = LN::pack(tw);
+          reinterpret_cast<WT *>(w_a + (size_t)k * np)[i] = LN::pack(tw);
         }
         reinterpret_cast<CT *>(p.cnt)[i] = LN::pack_c(cn);
       } else {
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
 #ifdef TSAMD_WGTIME
   {  // start / finish stamps of the workgroups of one first pass and one plain pass, kept in the unused tail of
      // the partial-row buffer and printed by workgroup 0 of the next first pass
-    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(p.partials + (size_t)2 * kMaxGrid * 2 * TSAMD_MAX_K) - 4 * kMaxGrid;
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(partials_a + (size_t)2 * kMaxGrid * 2 * TSAMD_MAX_K) - 4 * kMaxGrid;
     if (tid == 0 && idx == 41u && (FIRST || iters == 5u)) {
       stamps[(FIRST ? 0 : 2) * kMaxGrid + blockIdx.x] = wall_clock64();
       stamps[(FIRST ? 1 : 3) * kMaxGrid + blockIdx.x] = wg_t0;
