@@ -18,7 +18,9 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libtsamd.so")
 MAX_K = 32
 HEADERS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(ROOT, "include", "tsamd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+# -amdgpu-kernarg-preload-count: the leading scalar kernel arguments (ts_pass: control block, partial rows, weights,
+# geometry) arrive in SGPRs with the wave instead of through a kernel-argument load (gfx950 supports it)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-kernarg-preload-count=16",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("TSAMD_EXTRA_HIPCC_FLAGS", "").split()
 
 

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; K=$2; shift 2
 python -m terastructure_amd.build >/dev/null
 D=terastructure_amd/lib/variants; mkdir -p $D
-hipcc -c --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Iinclude -Iterastructure_amd/csrc \
+hipcc -c --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=16 -Iinclude -Iterastructure_amd/csrc \
   -DTSAMD_K=$K "$@" -o $D/inst_k${K}_$NAME.o terastructure_amd/csrc/tsamd_inst.hip
 OBJS=$(ls terastructure_amd/lib/obj/*.o | grep -v "inst_k${K}\.o")
 hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libtsamd_$NAME.so $OBJS $D/inst_k${K}_$NAME.o -ldl
