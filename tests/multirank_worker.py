@@ -26,6 +26,8 @@ def main():
     over = {}
     if os.environ.get("TS_CONV_THRESH"):      # early convergence: SNPs stop after differing pass counts
         over["conv_thresh"] = float(os.environ["TS_CONV_THRESH"])
+    if os.environ.get("TS_MAX_INNER"):
+        over["max_inner"] = int(os.environ["TS_MAX_INNER"])
     if os.environ.get("TS_DELAY_RANK") == str(rank):  # this rank stalls between its flag wait and its row reads
         os.environ["TSAMD_TEST_XCHG_DELAY_US"] = os.environ.get("TS_DELAY_US", "200")
     eng = ts.Engine(n, l, k, device=device, rank=rank, world=world, flags=int(os.environ.get("TS_FLAGS", "0")), **over)

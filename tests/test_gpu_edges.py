@@ -93,6 +93,32 @@ def test_pass_caps(ts, max_inner):
         assert_state_close(eng, orc, 1e-9, f"cap {max_inner}")
 
 
+@pytest.mark.parametrize("max_inner", [1, 2, 3, 10])
+@pytest.mark.parametrize("n", [900, 40_000])
+def test_schedules_with_pass_caps(ts, max_inner, n):
+    """Whole schedules (graph replay and eager launches) under small pass caps: with a cap of 1 every
+    launch is a first pass that finishes its predecessor; repeated locations take the slow path of
+    the first pass (values still in flight), everything else the fast path (NextSnp)."""
+    l, k = 12, 5
+    y, _, _ = psd_genotypes(n, l, k, 61, 0.03)
+    locs = np.array([3, 3, 7, 1, 7, 7, 7, 0, 2, 2, 5, 9, 11, 4, 4, 6, 8, 10, 3, 1, 0, 0, 5], dtype=np.uint32)
+    outs = []
+    for flags in (0, ts.FLAG_NO_GRAPH):
+        eng, orc = pair_from_y(ts, y, k, 62, flags=flags, max_inner=max_inner)
+        with eng:
+            eng.run_schedule(locs[:9])
+            eng.run_schedule(locs[9:10], 1)     # one validation-mode update in between
+            eng.run_schedule(locs[10:])
+            eng.synchronize()
+            if flags == 0:
+                its = [orc.snp_update(int(x), 1 if i == 9 else 0) for i, x in enumerate(locs)]
+                assert eng.total_passes() == sum(its) and max(its) <= max_inner
+                assert_state_close(eng, orc, 1e-9, f"cap {max_inner}")
+            outs.append((eng.get_lambda(), eng.get_gamma(), eng.get_counts()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_extreme_gamma_values(ts):
     """gamma from 1e-3 (psi = -1000: the weight underflows next to its neighbours) to 1e7."""
     n, l, k = 512, 8, 6

@@ -107,6 +107,18 @@ def test_p2p_early_convergence_with_a_lagging_rank(tmp_path, world, flags):
     _assert_ranks_match(res, orc, its)
 
 
+@pytest.mark.parametrize("world,max_inner", [(2, 1), (3, 2)])
+def test_p2p_small_pass_caps(tmp_path, world, max_inner):
+    """Pass caps of 1 and 2 over the peer-to-peer exchange: every (or every other) launch is a first
+    pass, whose workgroups other than 0 store their rows without having waited for peer rows (fast
+    path) and therefore rely on the progress guard; one rank lags."""
+    n, l, k, seed, nsnp = 3000, 32, 4, 23, 60
+    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp,
+                     extra_env={"TS_MAX_INNER": str(max_inner), "TS_DELAY_RANK": "0", "TS_DELAY_US": "100"})
+    orc, its = _oracle_run(n, l, k, seed, nsnp, online_iterations=max_inner)
+    _assert_ranks_match(res, orc, its)
+
+
 def test_rccl_two_ranks_matches_oracle(tmp_path):
     """The RCCL all-reduce exchange with more than one rank.  On a box with fewer GPUs than ranks
     RCCL refuses the communicator (two ranks on one device): skipped there, with RCCL's message."""
