@@ -16,5 +16,6 @@ bash tools/pmc.sh fetch20 FETCH_SIZE -- $A --pops 20 > $O/k20_pmc_fetch_size.txt
 bash tools/pmc.sh write20 WRITE_SIZE -- $A --pops 20 > $O/k20_pmc_write_size.txt 2>&1
 { for i in 1 2 3; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --no-profile 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('steps 20 warmup 5:', d['value'], 'updates/s', d['ms_per_step'], 'ms/step')"; done
   python3 bench.py --gpus 1 --steps 2000 --warmup 200 --cpu-seconds 0 --no-profile 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('steps 2000 warmup 200:', d['value'], 'updates/s', d['ms_per_step'], 'ms/step')"; } > $O/short_vs_long.txt 2>&1
+find gpurun_out -name "*.db" -delete  # (the summaries are what is kept; gpurun merges at most 64 MiB back)
 tail -n 12 $O/k8_kernel_trace.txt $O/k20_kernel_trace.txt $O/short_vs_long.txt | cut -c1-200
 for f in $O/k8_pmc_*.txt $O/k20_pmc_*.txt; do echo "== $f"; grep -E "ts_pass" $f | cut -c1-170 | head -20; done
