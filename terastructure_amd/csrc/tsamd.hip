@@ -111,6 +111,8 @@ struct tsamd_ctx {
   bool p2p = false;
   bool split = false;  // lambda_t leaves the pass via ctl->lt and the epilogue is its own kernel
   bool rccl_graph = false;  // TSAMD_RCCL_GRAPH=1: capture the RCCL all-reduce into the replayed graphs
+  bool resident = false;    // plain passes of a SNP run as ONE launch (ts_resident) instead of max_inner - 1
+  ResXchg *res = nullptr;   // its in-launch exchange buffer
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev_pass, ev_first;  // start/stop pairs
@@ -158,7 +160,8 @@ int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
 // launchers of the K-specialised kernels, one per translation unit (tsamd_inst.hip)
 #define TSAMD_DECL(k)                                                                              \
   void launch_k##k(int, uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, uint32_t); \
-  int first_blocks_per_cu_k##k(int);
+  int first_blocks_per_cu_k##k(int);                                                               \
+  int resident_blocks_per_cu_k##k();
 #define TSAMD_ALL_K(X)                                                                             \
   X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)     \
   X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
@@ -171,6 +174,8 @@ namespace {
 const LaunchFn kLaunchers[TSAMD_SPECIALIZED_K + 1] = {nullptr, TSAMD_ALL_K(TSAMD_ENTRY)};
 #define TSAMD_OCC_ENTRY(k) tsamd::first_blocks_per_cu_k##k,
 int (*const kFirstBlocksPerCu[TSAMD_SPECIALIZED_K + 1])(int) = {nullptr, TSAMD_ALL_K(TSAMD_OCC_ENTRY)};
+#define TSAMD_RES_ENTRY(k) tsamd::resident_blocks_per_cu_k##k,
+int (*const kResidentBlocksPerCu[TSAMD_SPECIALIZED_K + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_RES_ENTRY)};
 
 __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -258,7 +263,15 @@ int enqueue_snp(tsamd_ctx *c) {
       HIP_TRY(c, hipEventRecord(e, c->stream));
     }
   }
-  for (uint32_t i = 1; rc == TSAMD_OK && i < c->cfg.max_inner; ++i) rc = enqueue_pass(c, i);
+  if (c->resident) {  // every plain pass of the SNP in one launch
+    if (rc == TSAMD_OK) {
+      const uint32_t par = next_parity(c);
+      kLaunchers[c->cfg.k](kLaunchResident, c->grid, (uint32_t)kResidentBlock, c->stream, c->p, par, c->prev_rows);
+      c->prev_rows = c->grid;
+    }
+  } else {
+    for (uint32_t i = 1; rc == TSAMD_OK && i < c->cfg.max_inner; ++i) rc = enqueue_pass(c, i);
+  }
   if (prof && c->cfg.max_inner > 1 && rc == TSAMD_OK) {
     if (int rc2 = prof_event(c, c->ev_pass, 2 * c->n_ev_pass + 1, &e)) return rc2;
     HIP_TRY(c, hipEventRecord(e, c->stream));
@@ -279,7 +292,7 @@ void destroy_graph(tsamd_ctx *c) {
 }
 
 // kernels of the state-machine sequence per SNP (ts_reduce_rows shares its pass' parity)
-uint32_t kernels_per_snp(const tsamd_ctx *c) { return c->cfg.max_inner; }
+uint32_t kernels_per_snp(const tsamd_ctx *c) { return c->resident ? 2u : c->cfg.max_inner; }
 
 // Capture 2^level consecutive SNP sequences for launch parity par0 on entry.  Kernels read
 // everything that varies (location, pending state) from device memory; the only frozen
@@ -393,6 +406,7 @@ void activate_xchg(tsamd_ctx *c) {
   c->p.xchg_test_delay = env_u32("TSAMD_TEST_XCHG_DELAY_US", 0) * 100u;  // test hooks (tsamd_device.h)
   c->p.xchg_test_noguard = env_u32("TSAMD_TEST_XCHG_NOGUARD", 0);
   c->split = true;
+  c->resident = false;
   c->p2p = true;
   configure_launch(c, std::max<uint32_t>(16u, std::min<uint32_t>(kXchgBlocks, 512u / c->cfg.world)));
 }
@@ -501,6 +515,7 @@ void tsamd_destroy(tsamd_ctx *c) {
   hipFree(c->p.ctl);
   hipFree(c->p.partials);
   hipFree(c->d_sched);
+  hipFree(c->res);
   hipFree(c->d_hids);
   hipFree(c->d_hy);
   hipFree(c->d_hterms);
@@ -586,6 +601,16 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   }
   p.rows_from_lt = c->split ? 1u : 0u;
   p.sweep_alternate = env_u32("TSAMD_SWEEP", 1) ? 1u : 0u;
+  {
+    // Resident plain passes (ts_resident): one GPU, K <= 8, the shard's weights fit the register file
+    // (at most eight items per thread of a 256-thread workgroup) and every workgroup can be resident at once.
+    hipDeviceProp_t prop;
+    const int cus = hipGetDeviceProperties(&prop, c->dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    c->resident = !c->wide && !c->split && cfg->world == 1 && (int)cfg->k <= kResidentMaxK && c->block == 512u &&
+                  p.chunk <= (uint32_t)(kResidentItems * kResidentBlock) && (int)c->grid <= cus && c->grid <= (uint32_t)(kResGroups * kResMembers) &&
+                  cfg->max_inner >= 2 && cfg->max_inner <= 200 && env_u32("TSAMD_RESIDENT", 1) != 0u &&
+                  kResidentBlocksPerCu[cfg->k]() >= 1;
+  }
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
   CREATE_TRY(hipMalloc((void **)&p.w, K * np * sizeof(double)));
@@ -598,6 +623,11 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   c->sched_cap = 1024;
   CREATE_TRY(hipMalloc((void **)&c->d_sched, c->sched_cap * sizeof(uint32_t)));
 
+  if (c->resident) {
+    CREATE_TRY(hipMalloc((void **)&c->res, sizeof(ResXchg)));
+    CREATE_TRY(hipMemsetAsync(c->res, 0, sizeof(ResXchg), c->stream));
+    p.res = c->res;
+  }
   CREATE_TRY(hipMemsetAsync(p.bed, 0x55, L * p.colstride, c->stream));  // all missing
   CREATE_TRY(hipMemsetAsync(p.cnt, 0, np * sizeof(uint32_t), c->stream));
   CREATE_TRY(hipMemsetAsync(p.ctl, 0, sizeof(Ctl), c->stream));
@@ -1063,6 +1093,13 @@ int tsamd_synchronize(tsamd_ctx *c) {
     HIP_TRY(c, hipMemcpy(&err, &c->xchg->error, sizeof err, hipMemcpyDeviceToHost));
     if (err) return fail(c, TSAMD_ECOMM, "peer-to-peer exchange timed out waiting for a peer (epoch %llu)", err);
   }
+  if (c->resident) {
+    unsigned long long err = 0;
+    HIP_TRY(c, hipMemcpy(&err, &c->res->abort_word, sizeof err, hipMemcpyDeviceToHost));
+    if (err)
+      return fail(c, TSAMD_EHIP, "resident pass kernel: the in-launch exchange timed out (tag %llu): are all %u workgroups "
+                  "resident?  TSAMD_RESIDENT=0 selects one launch per pass", err, c->grid);
+  }
   if (c->prof) {
     for (uint32_t i = 0; i < c->n_ev_pass; ++i) {
       float ms = 0;
@@ -1140,7 +1177,8 @@ static int sync_held_table(tsamd_ctx *c) {
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (total > c->held_cap) {
-    hipFree(c->d_hids);
+    hipFree(c->res);
+  hipFree(c->d_hids);
     hipFree(c->d_hy);
     hipFree(c->d_hterms);
     c->d_hids = nullptr, c->d_hy = nullptr, c->d_hterms = nullptr, c->held_cap = 0;
@@ -1242,6 +1280,7 @@ int tsamd_comm_init(tsamd_ctx *c, const uint8_t id[TSAMD_COMM_ID_BYTES]) {
     return fail(c, TSAMD_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
   }
   c->split = true;
+  c->resident = false;
   c->p.rows_from_lt = 1u;
   c->rccl_graph = env_u32("TSAMD_RCCL_GRAPH", 0) != 0u;
   destroy_graph(c);

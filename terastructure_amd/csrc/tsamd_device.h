@@ -85,6 +85,24 @@ struct Xchg {
   unsigned long long error;  // a bounded wait gave up
 };
 
+// In-launch exchange of the resident plain-pass kernel (ts_resident; single GPU): per pass every
+// workgroup contributes its partial row and every workgroup gets the fixed-order total, as a
+// two-level all-reduce over 8-byte {tag, 32-bit half of a double} granules, each written by one
+// agent-scope store (the data is the flag: MI355X_MICROARCH.md, hand-off price list).
+//   level 1: the workgroups of group g = blockIdx % 8 publish rows[g][blockIdx / 8]; the group's
+//            leader (blockIdx < 8) re-reads them until every tag matches, adds them in member order
+//            and publishes sums[pass & 1][g];
+//   level 2: every workgroup re-reads the 8 leader rows and adds them in group order.
+// tag = 256 * launch epoch + pass: never repeats, so nothing is re-initialised between launches.
+constexpr int kResGroups = 8;
+constexpr int kResMembers = 32;  // workgroups per group (grid <= 256)
+constexpr int kResGran = 32;     // granules per row: 2 per value, 2K <= 16 values
+struct ResXchg {
+  unsigned long long rows[kResGroups][kResMembers][kResGran];
+  unsigned long long sums[2][kResGroups][kResGran];
+  unsigned long long abort_word;  // a bounded wait gave up (tag of the pass); later waits return at once
+};
+
 struct DevParams {
   uint8_t *bed;        // [l][colstride] 2-bit PLINK codes, shard-local, padding = missing
   uint64_t colstride;  // bytes per column (multiple of 128)
@@ -107,6 +125,7 @@ struct DevParams {
   uint32_t xchg_rank;
   Xchg *xchg;            // this rank's buffer
   Xchg *peers[kMaxRanks]; // every rank's buffer as mapped into this process (peers[xchg_rank] == xchg)
+  ResXchg *res;              // resident plain-pass kernel: its exchange buffer (NULL: launch per pass)
   uint32_t xchg_test_delay;  // test hook (TSAMD_TEST_XCHG_DELAY_US): stall between flag wait and row reads, 10 ns ticks
   uint32_t xchg_test_noguard; // test hook (TSAMD_TEST_XCHG_NOGUARD): skip the slot-reuse guard (to show the test sees the hazard)
   double alpha, eta0, eta1, nodetau0, nodekappa, gamma_scale, thresh;

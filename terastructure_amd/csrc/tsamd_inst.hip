@@ -34,9 +34,25 @@ void TSAMD_CAT(launch_k, TSAMD_K)(int which, uint32_t grid, uint32_t block, hipS
       else
         hipLaunchKernelGGL((ts_pass<K, true, 256, 1>), dim3(grid), dim3(256), 0, stream, TSAMD_PASS_ARGS(p.chunk_first));
       break;
+    case kLaunchResident:
+      if constexpr (K <= kResidentMaxK)
+        hipLaunchKernelGGL((ts_resident<K>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.partials, p.w, p.npad, p.chunk, par,
+                           nrows_hint, p.res, p);
+      break;
     default:
       hipLaunchKernelGGL((ts_refresh_w<K>), dim3((p.npairs + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, p);
       break;
+  }
+}
+
+// can a 512-thread workgroup of the resident plain-pass kernel run on a compute unit (register budget)?
+int TSAMD_CAT(resident_blocks_per_cu_k, TSAMD_K)() {
+  constexpr int K = TSAMD_K;
+  if constexpr (K <= kResidentMaxK) {
+    int nb = 0;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ts_resident<K>, kResidentBlock, 0) == hipSuccess ? nb : 0;
+  } else {
+    return 0;
   }
 }
 

@@ -89,6 +89,34 @@ __device__ __forceinline__ PendingIn load_pending(const State *S, uint32_t J) {
   in.iters = S->iters;
   return in;
 }
+// The K x 2 epilogue proper, for thread tid < J holding lt = the row total of value tid:
+// lambda_t = eb_used * lt, update_lambda, estimate_beta; outputs into LDS.  Called by threads < J.
+__device__ __forceinline__ void epilogue_values(const DevParams &p, double lt, double eb_used, double lam_old,
+                                                double *s_lam, double *s_eb, double *s_diff) {
+  const uint32_t tid = threadIdx.x;
+  // eta + b[k,t] * (row sum): the b factored out of the accumulation; an explicit fma so that
+  // every kernel that inlines this rounds the same way whatever the compiler would contract
+  const double nw = fma(lt, eb_used, (tid & 1u) ? p.eta1 : p.eta0);
+  // exp(Elogbeta_kt) = exp(psi(lambda_kt) - psi(lambda_k0 + lambda_k1)) without a log: both
+  // digammas in the split form z * exp(a) (tsamd_device.h), side by side in one instruction
+  // stream; the pair sum comes from the neighbouring lane (t = 0/1 are adjacent threads)
+  const double pair = nw + partner<1>(nw);
+  double z1, a1, z2, a2;
+  exp_digamma_split(nw, z1, a1);
+  exp_digamma_split(pair, z2, a2);
+  s_lam[tid] = nw;
+  s_eb[tid] = (z1 * fast_rcp(z2)) * exp_nonpos(a1 - a2);
+  s_diff[tid] = fabs(nw - lam_old);
+}
+// ... and the convergence decision every thread takes for itself after the barrier that follows:
+// mean |dlambda| in the reference's order j = 0 .. J-1 (abs_mean, src/matrix.hh:885-893)
+__device__ __forceinline__ bool epilogue_complete(const DevParams &p, uint32_t iters, uint32_t J, const double *s_diff) {
+  double d = 0.0;
+  for (uint32_t jj = 0; jj < J; ++jj) d += s_diff[jj];
+  d /= (double)J;
+  return d < p.thresh || iters >= p.max_inner;
+}
+
 template <int BLOCK>
 __device__ __forceinline__ bool finish_pending(const DevParams &p, const PendingIn &in, double v, uint32_t J,
                                                double *s_fin, double *s_lam, double *s_eb, double *s_diff) {
@@ -99,27 +127,10 @@ __device__ __forceinline__ bool finish_pending(const DevParams &p, const Pending
   if (tid < J) {
     double lt = 0.0;
     for (uint32_t rr = 0; rr < R; ++rr) lt += s_fin[rr * J + tid];
-    // eta + b[k,t] * (row sum): the b factored out of the accumulation; an explicit fma so that
-    // every kernel that inlines this rounds the same way whatever the compiler would contract
-    const double nw = fma(lt, in.eb_used, (tid & 1u) ? p.eta1 : p.eta0);
-    // exp(Elogbeta_kt) = exp(psi(lambda_kt) - psi(lambda_k0 + lambda_k1)) without a log: both
-    // digammas in the split form z * exp(a) (tsamd_device.h), side by side in one instruction
-    // stream; the pair sum comes from the neighbouring lane (t = 0/1 are adjacent threads)
-    const double pair = nw + partner<1>(nw);
-    double z1, a1, z2, a2;
-    exp_digamma_split(nw, z1, a1);
-    exp_digamma_split(pair, z2, a2);
-    s_lam[tid] = nw;
-    s_eb[tid] = (z1 * fast_rcp(z2)) * exp_nonpos(a1 - a2);
-    s_diff[tid] = fabs(nw - in.lam_old);
+    epilogue_values(p, lt, in.eb_used, in.lam_old, s_lam, s_eb, s_diff);
   }
   __syncthreads();
-  // every thread takes the convergence decision itself (saves a barrier): mean |dlambda| in
-  // the reference's order j = 0 .. J-1
-  double d = 0.0;
-  for (uint32_t jj = 0; jj < J; ++jj) d += s_diff[jj];
-  d /= (double)J;
-  return d < p.thresh || in.iters >= p.max_inner;
+  return epilogue_complete(p, in.iters, J, s_diff);
 }
 
 // workgroup 0 publishes the completed SNP: final lambda / exp(Elogbeta) into the global
@@ -151,6 +162,32 @@ __device__ __forceinline__ void publish_complete(const DevParams &p, Ctl *ctl, c
       W->nrows = 0u;
       W->epoch = S->epoch + 1ull;
     }
+  }
+}
+
+// the same for a kernel that ran several passes itself: everything explicit instead of read from S
+__device__ __forceinline__ void publish_complete_v(const DevParams &p, Ctl *ctl, State *W, uint32_t J, uint32_t idx,
+                                                   uint32_t loc, uint32_t hol, uint32_t iters, unsigned long long epoch_now,
+                                                   double eb_last, const double *s_lam, const double *s_eb) {
+  const uint32_t tid = threadIdx.x;
+  if (tid < J) {
+    p.lam[(size_t)loc * J + tid] = s_lam[tid];
+    p.eb[(size_t)loc * J + tid] = s_eb[tid];
+    W->lam[tid] = s_lam[tid];
+    W->eb[tid] = eb_last;  // exp(Elogbeta) the LAST executed pass used (the deferred gamma step needs it)
+  }
+  if (tid == 0) {
+    ctl->last_iters = iters;
+    ctl->total_passes += (unsigned long long)iters;
+    ctl->pass_hist[min(iters, (uint32_t)TSAMD_PASS_HIST_BINS - 1u)] += 1ull;
+    W->idx = idx;
+    W->valid = 1u;
+    W->loc = loc;
+    W->hol = hol;
+    W->iters = iters;
+    W->done = 1u;
+    W->nrows = 0u;
+    W->epoch = epoch_now;
   }
 }
 
@@ -810,6 +847,288 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
 #endif
 }
 
+
+// ---------------------------------------------------------------------------
+// ts_resident<K>: ALL plain passes of a SNP in one launch (single GPU, K <= 8, at most eight items
+// per thread, i.e. N <= ~1M: the shard's weights fit the register file -- 256 CUs x 256 threads x
+// 8 items x K rows x 16 bytes = 64 MB at K = 8).  The first of its passes streams the weights
+// exactly like ts_pass<K,false,512,2> and keeps them; every later pass runs from registers.
+// Between passes the workgroups exchange their partial rows inside the launch (ResXchg,
+// tsamd_device.h): measured 3.1 us per exchange (tools/xchg_probe.hip), about what a kernel
+// boundary + state reload + row reads cost -- so the gain is the 5 us weight sweep of every pass
+// after the first.  Same state machine as the launch-per-pass sequence: it starts from the
+// first pass' State and partial rows and leaves State / partial rows for the next first pass (or
+// ts_flush); the workgroups reach the complete / continue decision identically from the same
+// totals.  Needs every workgroup resident at once (grid <= CUs, checked by the host); every wait
+// is bounded and a failure ends all later waits (reported by tsamd_synchronize).
+constexpr int kResidentMaxK = 8;    // ts_resident holds kResidentItems items x K rows x 16 bytes per thread in registers
+constexpr int kResidentItems = 8;   // (256-thread workgroups, one per compute unit)
+constexpr int kResidentBlock = 256;
+
+template <int N>
+__device__ __forceinline__ bool res_sweep(const unsigned long long *base, uint32_t tag, uint32_t nvalid_gran, uint32_t group,
+                                          uint32_t grid, bool by_member, unsigned (&v)[N], unsigned long long *abort_word) {
+  // lane l, load i: granule c = l % 32 of row 2 i + (l >= 32); a row is a member's (level 1: it
+  // exists if member * 8 + group < grid) or a group's (level 2: group index < min(grid, 8))
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t c = lane & 31u;
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t row = 2u * (uint32_t)i + (lane >> 5);
+      const bool exists = c < nvalid_gran && (by_member ? row * (uint32_t)kResGroups + group < grid : row < min(grid, (uint32_t)kResGroups));
+      const unsigned long long x = __hip_atomic_load(base + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v[i] = exists ? (unsigned)x : 0u;
+      ok &= !exists || (unsigned)(x >> 32) == tag;
+    }
+    if (__all(ok)) return true;
+    if (wall_clock64() - t0 > 300000000ull ||  // 3 s
+        __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
+      if (lane == 0) __hip_atomic_store(abort_word, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// sum of the N rows a wave has swept (lo / hi halves of a double sit in neighbouring lanes): on
+// return lane 2 j (j < J) holds the total of value j over rows 0, 2, 4, ... plus rows 1, 3, 5, ...
+template <int N>
+__device__ __forceinline__ double res_sum(const unsigned (&v)[N]) {
+  const uint32_t lane = threadIdx.x & 63u;
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const unsigned other = (unsigned)__shfl_xor((int)v[i], 1);
+    const unsigned lo = (lane & 1u) ? other : v[i], hi = (lane & 1u) ? v[i] : other;
+    s += __longlong_as_double(((unsigned long long)hi << 32) | lo);
+  }
+  return s + __shfl_xor(s, 32);
+}
+
+template <int KT>
+__global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partials_a, double *w_a, uint32_t npad_a, uint32_t chunk_a,
+                                                      uint32_t par_arg, uint32_t nrows_hint, ResXchg *xb, const DevParams p) {
+  // 256 threads, one wave per SIMD: the whole 512-register file per lane is this wave's (8 items x K
+  // rows x 4 registers = 256 at K = 8, plus accumulators and temporaries)
+  constexpr int BLOCK = 256, kWaves = BLOCK / 64, kItems = kResidentItems;
+  using WT = double2;
+  constexpr uint32_t kItemsPerWord = 8u, kCodeBits = 4u;
+  constexpr uint32_t J = 2 * KT;
+  static_assert(2 * J <= (uint32_t)kResGran, "row does not fit the exchange granules");
+  __shared__ double s_eb[J], s_lam[J], s_diff[J], s_tot[J];
+  __shared__ double s_red[kWaves][J];
+  __shared__ double s_fin[BLOCK];
+  __shared__ int s_alive;
+
+  const uint32_t par = par_arg & 1u;
+  Ctl *ctl = ctl_a;
+  const State *S = &ctl->st[par ^ 1u];
+  State *W = &ctl->st[par];
+  const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
+  const uint32_t siters = S->iters, snrows = S->nrows;
+  __builtin_amdgcn_sched_barrier(0);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const size_t np = npad_a;
+  const uint32_t nitems = npad_a / 2u;
+  const uint32_t begin = blockIdx.x * chunk_a, end = min(begin + chunk_a, nitems);
+  const uint32_t i0 = begin + tid;
+  const uint32_t cnt = (i0 < end) ? min((end - i0 + BLOCK - 1u) / BLOCK, (uint32_t)kItems) : 0u;
+  auto item_or_last = [&](uint32_t t) { return cnt ? i0 + min(t, cnt - 1u) * BLOCK : min(i0, nitems - 1u); };
+  auto load_rows = [&](uint32_t i, WT (&wv)[KT]) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) wv[k] = reinterpret_cast<const WT *>(w_a + (size_t)k * np)[i];
+  };
+
+  // the first pass' partial rows and the epilogue's inputs first, then the first item's rows
+  RowSum<BLOCK> rowsum;
+  rowsum.issue(partials_a + (size_t)(par ^ 1u) * kMaxGrid * J, nrows_hint, J);
+  const PendingIn pin = load_pending(S, J);
+  WT buf[kItems][KT];
+  load_rows(item_or_last(0), buf[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  uint32_t word[kItems];
+  {
+    const uint32_t *col = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride);
+#pragma unroll
+    for (int t = 0; t < kItems; ++t) word[t] = col[item_or_last((uint32_t)t) / kItemsPerWord];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  const bool pending = svalid != 0u && sdone == 0u;
+  const unsigned long long epoch_now = S->epoch + 1ull;
+  if (!pending) {  // nothing in flight (schedule exhausted, dry replay): carry the state forward
+    if (blockIdx.x == 0) carry_state(S, W, J);
+    return;
+  }
+  const double vrow = (snrows == nrows_hint) ? rowsum.finish()
+                                             : row_partial_sum<BLOCK>(partials_a + (size_t)(par ^ 1u) * kMaxGrid * J, snrows, J);
+  bool complete = finish_pending<BLOCK>(p, pin, vrow, J, s_fin, s_lam, s_eb, s_diff);
+  uint32_t iters = siters;
+  double eb_used = pin.eb_used;  // (threads < J) exp(Elogbeta) the last executed pass used
+  const uint32_t g = blockIdx.x % (uint32_t)kResGroups, m = blockIdx.x / (uint32_t)kResGroups;
+  double lam_old = 0.0;
+  double b0[KT], b1[KT], acc0[KT], acc1[KT];
+  // start of a pass: the values the previous epilogue left in LDS become this pass' inputs
+  auto begin_pass = [&]() {
+    iters += 1u;
+    lam_old = s_lam[tid < J ? tid : 0u];
+    eb_used = s_eb[tid < J ? tid : 0u];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      b0[k] = uniform_f64(s_eb[2 * k]);
+      b1[k] = uniform_f64(s_eb[2 * k + 1]);
+      acc0[k] = acc1[k] = 0.0;
+    }
+  };
+  auto consume = [&](uint32_t i, const WT (&wv)[KT], uint32_t wd) {
+    const uint32_t code = wd >> (kCodeBits * (i % kItemsPerWord));
+    double c0[2], c1[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      double mom, dad;
+      bool ok;
+      code_weights((code >> (2 * v)) & 3u, mom, dad, ok);
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const double wk = v ? wv[k].y : wv[k].x;
+        s0 = fma(wk, b0[k], s0);
+        s1 = fma(wk, b1[k], s1);
+      }
+      c0[v] = mom * fast_rcp(s0);  // (arithmetic-bound from the second sweep on)
+      c1[v] = dad * fast_rcp(s1);
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      acc0[k] = fma(c0[1], wv[k].y, acc0[k]);
+      acc1[k] = fma(c1[1], wv[k].y, acc1[k]);
+      acc0[k] = fma(c0[0], wv[k].x, acc0[k]);
+      acc1[k] = fma(c1[0], wv[k].x, acc1[k]);
+    }
+  };
+  // end of a pass: workgroup reduction; then either (the cap) hand rows and state to the next launch,
+  // or exchange the rows inside the launch and run the epilogue.  Returns true when the kernel is over.
+  auto finish_pass = [&]() -> bool {
+    {
+      using Fold = WaveFold<2 * KT>;  // fixed order: lanes (halving butterfly) -> waves
+      double v[Fold::P];
+#pragma unroll
+      for (int q = 0; q < Fold::P; ++q) v[q] = 0.0;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        v[2 * k] = acc0[k];
+        v[2 * k + 1] = acc1[k];
+      }
+      const double tot = Fold::fold(v, lane);
+      const int slot = Fold::slot(lane);
+      constexpr uint32_t kRep = 64 / Fold::P;
+      if ((lane & (kRep - 1u)) == 0u && slot < (int)J) s_red[wave][slot] = tot;
+    }
+    __syncthreads();
+    double row = 0.0;
+    if (tid < J) {
+      row = s_red[0][tid];
+#pragma unroll
+      for (int wv = 1; wv < kWaves; ++wv) row += s_red[wv][tid];
+    }
+    if (iters >= p.max_inner) {
+      // the cap: this was the SNP's last pass; its rows and the state go to the next launch (a first
+      // pass or ts_flush), exactly as the last plain pass of the launch-per-pass sequence leaves them
+      if (tid < J) (partials_a + (size_t)par * kMaxGrid * J)[(size_t)blockIdx.x * J + tid] = row;
+      if (blockIdx.x == 0) {
+        if (tid < J) {
+          W->lam[tid] = lam_old;
+          W->eb[tid] = eb_used;
+        }
+        if (tid == 0) {
+          W->idx = sidx;
+          W->valid = 1u;
+          W->loc = sloc;
+          W->hol = shol;
+          W->iters = iters;
+          W->done = 0u;
+          W->nrows = gridDim.x;
+          W->epoch = epoch_now;
+        }
+      }
+      return true;
+    }
+    // ---- in-launch exchange of the partial rows ---------------------------------------------
+    const uint32_t tag = (uint32_t)(epoch_now << 8) + iters;
+    if (tid < J) {
+      const unsigned long long bits = __double_as_longlong(row);
+      __hip_atomic_store(&xb->rows[g][m][2 * tid], ((unsigned long long)tag << 32) | (uint32_t)bits, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&xb->rows[g][m][2 * tid + 1], ((unsigned long long)tag << 32) | (uint32_t)(bits >> 32), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave == 0) {
+      bool alive = true;
+      if (m == 0) {  // leader of group g
+        unsigned v[kResMembers / 2];
+        alive = res_sweep<kResMembers / 2>(&xb->rows[g][0][0], tag, 2 * J, g, gridDim.x, true, v, &xb->abort_word);
+        const double s = res_sum<kResMembers / 2>(v);
+        if (lane < 2 * J && !(lane & 1u)) {
+          const unsigned long long bits = __double_as_longlong(s);
+          __hip_atomic_store(&xb->sums[iters & 1u][g][lane], ((unsigned long long)tag << 32) | (uint32_t)bits, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&xb->sums[iters & 1u][g][lane + 1], ((unsigned long long)tag << 32) | (uint32_t)(bits >> 32),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      unsigned v2[kResGroups / 2];
+      alive = res_sweep<kResGroups / 2>(&xb->sums[iters & 1u][0][0], tag, 2 * J, 0u, gridDim.x, false, v2, &xb->abort_word) && alive;
+      const double s = res_sum<kResGroups / 2>(v2);
+      if (lane < 2 * J && !(lane & 1u)) s_tot[lane >> 1] = s;
+      if (lane == 0) s_alive = alive ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_alive) return true;  // (the abort word is set: tsamd_synchronize reports it; the state is void)
+    if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);
+    __syncthreads();
+    complete = epilogue_complete(p, iters, J, s_diff);
+    return false;
+  };
+  auto publish = [&]() {
+    if (blockIdx.x == 0) publish_complete_v(p, ctl, W, J, sidx, sloc, shol, iters, epoch_now, eb_used, s_lam, s_eb);
+  };
+
+  if (complete) {  // (the first pass was the SNP's last)
+    publish();
+    return;
+  }
+  // first sweep: stream the weights like the plain pass (the next two items' rows in flight while the
+  // current one is reduced; clamped, unconditional loads) -- and keep them
+  begin_pass();
+  load_rows(item_or_last(1u), buf[1]);
+#pragma unroll
+  for (int t = 0; t < kItems; ++t) {
+    if (t + 2 < kItems) load_rows(item_or_last((uint32_t)t + 2u), buf[t + 2]);
+    __builtin_amdgcn_sched_barrier(0);
+    if ((uint32_t)t < cnt) consume(i0 + (uint32_t)t * BLOCK, buf[t], word[t]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (finish_pass()) return;
+  // every later sweep runs from registers (one item at a time: interleaving them would only
+  // multiply the temporaries)
+  for (;;) {
+    if (complete) {
+      publish();
+      return;
+    }
+    begin_pass();
+#pragma unroll
+    for (int t = 0; t < kItems; ++t) {
+      if ((uint32_t)t < cnt) consume(i0 + (uint32_t)t * BLOCK, buf[t], word[t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (finish_pass()) return;
+  }
+}
+
 #ifdef TSAMD_MAIN_TU  // K-independent kernels: compiled into tsamd.hip only
 // End of a schedule: complete the pending pass so that lambda/eb in the global arrays are
 // final (whole SNPs only are ever enqueued, so the pending pass is the SNP's last).
@@ -907,7 +1226,7 @@ __global__ __launch_bounds__(kBlock) void ts_refresh_w(DevParams p) {
 
 // Host-side launcher of the K-specialised kernels; one translation unit per K
 // (tsamd_inst.hip compiled with -DTSAMD_K=<k>) defines tsamd::launch_k<k>.
-enum LaunchWhich { kLaunchPass = 0, kLaunchFirst = 1, kLaunchRefresh = 2 };
+enum LaunchWhich { kLaunchPass = 0, kLaunchFirst = 1, kLaunchRefresh = 2, kLaunchResident = 3 };
 using LaunchFn = void (*)(int which, uint32_t grid, uint32_t block, hipStream_t stream, const DevParams &p,
                           uint32_t par, uint32_t nrows_hint);
 

@@ -45,10 +45,14 @@ CALLS = [([3, 3, 5, 1, 6, 1, 2, 0, 7, 7, 4, 5, 3, 6, 2, 1, 0], 0), ([5], 1), ([6
 
 
 @pytest.mark.parametrize("n,k,thresh", [(300_000, 8, None), (1_000_000, 8, None), (125_000, 20, None),
-                                        (1_000_000, 20, None), (300_000, 8, 20.0), (1_000_000, 20, 40.0)])
+                                        (1_000_000, 20, None), (300_000, 8, 20.0), (1_000_000, 20, 40.0),
+                                        (600_000, 8, None), (600_000, 8, 30.0), (600_000, 8, 40.0)])
 def test_benchmarked_geometry_matches_oracle(ts, n, k, thresh):
     """run_schedule (hipGraph replay) and eager snp_update calls at N up to 1M, K = 8 and 20;
-    `thresh` raises meanchangethresh so that SNPs stop after differing numbers of passes."""
+    `thresh` raises meanchangethresh so that SNPs stop after differing numbers of passes.  From
+    N = 512K at K <= 8 the plain passes of a SNP run as ONE resident launch (ts_resident: weights in
+    registers, in-launch exchange of the partial rows); N = 600K puts six items in each of its threads
+    and, with a threshold, ends its pass loop after 1 ... 10 passes."""
     l = 8
     y, _, _ = psd_genotypes(n, l, k, 4000 + k, 0.02)
     payload = pack_bed(y)
