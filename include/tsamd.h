@@ -239,6 +239,10 @@ int tsamd_profile_read(tsamd_ctx *ctx, uint64_t *pass_launches, double *pass_ms_
  * the values are written back unchanged).  Averages over reps launches (HIP events).  The
  * wide-K fallback (k > TSAMD_SPECIALIZED_K) is probed with the same two kernels. */
 int tsamd_probe_stream(tsamd_ctx *ctx, uint32_t reps, double *read_us, double *rmw_us);
+/* how the context runs a SNP: kernels per SNP of the state-machine sequence (max_inner with one launch per
+ * pass; 2 when all plain passes of a SNP run as one resident launch: single GPU, k <= 8, shards up to ~1M
+ * individuals, TSAMD_RESIDENT=0 disables), workgroups of the plain-pass and first-pass kernels */
+int tsamd_launch_info(tsamd_ctx *ctx, uint32_t *kernels_per_snp, uint32_t *plain_grid, uint32_t *first_grid);
 /* device memory in bytes currently free / total on the context's device */
 int tsamd_mem_info(tsamd_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 

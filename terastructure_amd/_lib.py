@@ -77,6 +77,7 @@ SYMBOLS = {
     "tsamd_profile_enable": (_int, [_vp, _int]),
     "tsamd_profile_read": (_int, [_vp, _pu64, _pd, _pu64, _pd]),
     "tsamd_probe_stream": (_int, [_vp, _u32, _pd, _pd]),
+    "tsamd_launch_info": (_int, [_vp, _pu32, _pu32, _pu32]),
     "tsamd_mem_info": (_int, [_vp, _pu64, _pu64]),
 }
 

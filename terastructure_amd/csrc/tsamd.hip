@@ -337,7 +337,9 @@ int build_all_graphs(tsamd_ctx *c) {
 bool graphs_allowed(const tsamd_ctx *c) {
   // (RCCL all-reduce inside the captured sequence: opt-in, TSAMD_RCCL_GRAPH=1 on every rank)
   const bool comm_graph = c->comm && !c->p2p && c->rccl_graph;
-  return !(c->cfg.flags & TSAMD_FLAG_NO_GRAPH) && (!c->comm || c->p2p || comm_graph) && !c->prof;
+  // (resident plain passes: two launches per SNP of ~50 us each -- eager launches stay far ahead of the
+  // device and have neither the submission cost of a graph nor the ~8 us boundary between graphs)
+  return !(c->cfg.flags & TSAMD_FLAG_NO_GRAPH) && (!c->comm || c->p2p || comm_graph) && !c->prof && !c->resident;
 }
 
 // the graphs are built on first use; with an RCCL all-reduce inside, the first collective runs
@@ -1487,6 +1489,14 @@ int tsamd_probe_stream(tsamd_ctx *c, uint32_t reps, double *read_us, double *rmw
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   if (e != hipSuccess) return fail(c, TSAMD_EHIP, "probe_stream: %s", hipGetErrorString(e));
+  return TSAMD_OK;
+}
+
+int tsamd_launch_info(tsamd_ctx *c, uint32_t *kernels_per_snp_out, uint32_t *plain_grid, uint32_t *first_grid) {
+  CHECK_CTX(c);
+  if (kernels_per_snp_out) *kernels_per_snp_out = kernels_per_snp(c);
+  if (plain_grid) *plain_grid = c->grid;
+  if (first_grid) *first_grid = c->grid_first;
   return TSAMD_OK;
 }
 

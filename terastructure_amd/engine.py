@@ -287,6 +287,12 @@ class Engine:
         self._check(self.h.tsamd_probe_stream(self.ctx, reps, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def launch_info(self):
+        """dict(kernels_per_snp, plain_grid, first_grid) -- tsamd_launch_info"""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._check(self.h.tsamd_launch_info(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(kernels_per_snp=a.value, plain_grid=b.value, first_grid=c.value)
+
     def mem_info(self):
         f, t = C.c_uint64(0), C.c_uint64(0)
         self._check(self.h.tsamd_mem_info(self.ctx, C.byref(f), C.byref(t)))

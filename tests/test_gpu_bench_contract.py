@@ -32,7 +32,7 @@ def test_bench_json_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
     assert "N=30000 K=8" in d["metric"]                                       # names the workload that ran
-    assert rf["probe_read_us"] > 0 and "Infinity Cache" in rf["ceiling_note"]
+    assert rf["probe_read_us"] > 0 and "tsamd_probe_stream" in rf["ceiling_note"] and rf["passes_per_launch"] == 1.0
     fp = rf["first_pass"]
     assert fp["bound"] == "hbm" and abs(fp["frac"] - fp["achieved"] / fp["peak"]) < 1e-3 and fp["probe_rmw_us"] > 0
     assert fp["algorithmic_bytes_per_launch"] == 32.0 * 30000 * 8 + 8.0 * 30000 + 30000 / 2.0
