@@ -113,6 +113,7 @@ struct tsamd_ctx {
   bool rccl_graph = false;  // TSAMD_RCCL_GRAPH=1: capture the RCCL all-reduce into the replayed graphs
   bool resident = false;    // plain passes of a SNP run as ONE launch (ts_resident) instead of max_inner - 1
   ResXchg *res = nullptr;   // its in-launch exchange buffer
+  unsigned long long *h_error = nullptr;  // pinned: tag of a bounded in-kernel wait that gave up (0: none)
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev_pass, ev_first;  // start/stop pairs
@@ -220,8 +221,8 @@ int enqueue_pass(tsamd_ctx *c, uint32_t pass) {
   return TSAMD_OK;
 }
 
-void enqueue_begin(tsamd_ctx *c, uint32_t n, bool drop_pending) {
-  hipLaunchKernelGGL(ts_begin, dim3(1), dim3(256), 0, c->stream, c->p, (const uint32_t *)c->d_sched, n, next_parity(c),
+void enqueue_begin(tsamd_ctx *c, uint32_t n, bool drop_pending, const uint32_t *host_sched = nullptr) {
+  hipLaunchKernelGGL(ts_begin, dim3(1), dim3(256), 0, c->stream, c->p, host_sched, c->d_sched, n, next_parity(c),
                      drop_pending ? 1u : 0u);
 }
 
@@ -518,6 +519,7 @@ void tsamd_destroy(tsamd_ctx *c) {
   hipFree(c->p.partials);
   hipFree(c->d_sched);
   hipFree(c->res);
+  if (c->h_error) hipHostFree(c->h_error);
   hipFree(c->d_hids);
   hipFree(c->d_hy);
   hipFree(c->d_hterms);
@@ -625,6 +627,9 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   c->sched_cap = 1024;
   CREATE_TRY(hipMalloc((void **)&c->d_sched, c->sched_cap * sizeof(uint32_t)));
 
+  CREATE_TRY(hipHostMalloc((void **)&c->h_error, sizeof(unsigned long long), hipHostMallocDefault));
+  *c->h_error = 0ull;
+  p.host_error = c->h_error;
   if (c->resident) {
     CREATE_TRY(hipMalloc((void **)&c->res, sizeof(ResXchg)));
     CREATE_TRY(hipMemsetAsync(c->res, 0, sizeof(ResXchg), c->stream));
@@ -1027,14 +1032,13 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
     HIP_TRY(c, hipMalloc((void **)&c->d_sched, (size_t)cap * sizeof(uint32_t)));
     c->sched_cap = cap;  // (the kernels take the pointer from Ctl, written by ts_begin)
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_sched, ent, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   // Everything that varies per SNP is read from device memory, so captured sequences of
   // 16, 8, 4, 2 and 1 SNPs are replayed as often as the schedule length needs (binary
   // decomposition: nothing is padded); results are identical to eager launches bit for bit.
   const bool use_graph = graphs_allowed(c);
   if (use_graph)
     if (int rc = ensure_graphs(c)) return rc;
-  enqueue_begin(c, n, false);
+  enqueue_begin(c, n, false, ent);  // (ts_begin copies the entries out of the pinned buffer itself)
   if (use_graph) {
     const uint32_t per_snp = kernels_per_snp(c);
     uint32_t left = n;
@@ -1073,7 +1077,7 @@ int tsamd_prepare(tsamd_ctx *c) {
   // here.  With no schedule in progress every kernel of the sequence only carries the state
   // forward (sharded: all ranks call tsamd_prepare alike, so the launch sequences stay aligned).
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  hipLaunchKernelGGL(ts_begin, dim3(1), dim3(256), 0, c->stream, c->p, (const uint32_t *)c->d_sched, 0u, next_parity(c), 0u);
+  hipLaunchKernelGGL(ts_begin, dim3(1), dim3(256), 0, c->stream, c->p, (const uint32_t *)nullptr, c->d_sched, 0u, next_parity(c), 0u);
   for (uint32_t level = 0; level < kGraphLevels; ++level)
     for (uint32_t par0 = 0; par0 < 2; ++par0) {
       if ((uint32_t)(c->q & 1u) != par0) enqueue_begin(c, 0xffffffffu, false);
@@ -1090,17 +1094,11 @@ int tsamd_synchronize(tsamd_ctx *c) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->sched_free.insert(c->sched_free.end(), c->sched_busy.begin(), c->sched_busy.end());
   c->sched_busy.clear();
-  if (c->p2p) {
-    unsigned long long err = 0;
-    HIP_TRY(c, hipMemcpy(&err, &c->xchg->error, sizeof err, hipMemcpyDeviceToHost));
-    if (err) return fail(c, TSAMD_ECOMM, "peer-to-peer exchange timed out waiting for a peer (epoch %llu)", err);
-  }
-  if (c->resident) {
-    unsigned long long err = 0;
-    HIP_TRY(c, hipMemcpy(&err, &c->res->abort_word, sizeof err, hipMemcpyDeviceToHost));
-    if (err)
-      return fail(c, TSAMD_EHIP, "resident pass kernel: the in-launch exchange timed out (tag %llu): are all %u workgroups "
-                  "resident?  TSAMD_RESIDENT=0 selects one launch per pass", err, c->grid);
+  if (c->h_error && *(volatile unsigned long long *)c->h_error != 0ull) {  // (written by the kernel that gave up)
+    const unsigned long long err = *(volatile unsigned long long *)c->h_error;
+    if (c->p2p) return fail(c, TSAMD_ECOMM, "peer-to-peer exchange timed out waiting for a peer (epoch %llu)", err);
+    return fail(c, TSAMD_EHIP, "resident pass kernel: the in-launch exchange timed out (tag %llu): are all %u workgroups "
+                "resident?  TSAMD_RESIDENT=0 selects one launch per pass", err, c->grid);
   }
   if (c->prof) {
     for (uint32_t i = 0; i < c->n_ev_pass; ++i) {
@@ -1180,6 +1178,7 @@ static int sync_held_table(tsamd_ctx *c) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (total > c->held_cap) {
     hipFree(c->res);
+  if (c->h_error) hipHostFree(c->h_error);
   hipFree(c->d_hids);
     hipFree(c->d_hy);
     hipFree(c->d_hterms);

@@ -233,6 +233,7 @@ __device__ __forceinline__ void wait_peer_rows(const DevParams &p, uint32_t slot
       __builtin_amdgcn_s_sleep(4);
       if (wall_clock64() - start > 300000000ull) {  // 3 s: a peer died; report instead of hanging
         __hip_atomic_store(&p.xchg->error, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.host_error) __hip_atomic_store(p.host_error, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
     }
@@ -260,6 +261,7 @@ __device__ __forceinline__ void wait_peer_progress(const DevParams &p, unsigned 
     __builtin_amdgcn_s_sleep(4);
     if (wall_clock64() - start > 300000000ull) {  // 3 s
       __hip_atomic_store(&p.xchg->error, epoch_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (p.host_error) __hip_atomic_store(p.host_error, epoch_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
   }
@@ -867,7 +869,8 @@ constexpr int kResidentBlock = 256;
 
 template <int N>
 __device__ __forceinline__ bool res_sweep(const unsigned long long *base, uint32_t tag, uint32_t nvalid_gran, uint32_t group,
-                                          uint32_t grid, bool by_member, unsigned (&v)[N], unsigned long long *abort_word) {
+                                          uint32_t grid, bool by_member, unsigned (&v)[N], unsigned long long *abort_word,
+                                          unsigned long long *host_flag) {
   // lane l, load i: granule c = l % 32 of row 2 i + (l >= 32); a row is a member's (level 1: it
   // exists if member * 8 + group < grid) or a group's (level 2: group index < min(grid, 8))
   const uint32_t lane = threadIdx.x & 63u;
@@ -886,7 +889,10 @@ __device__ __forceinline__ bool res_sweep(const unsigned long long *base, uint32
     if (__all(ok)) return true;
     if (wall_clock64() - t0 > 300000000ull ||  // 3 s
         __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
-      if (lane == 0) __hip_atomic_store(abort_word, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) {
+        __hip_atomic_store(abort_word, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (host_flag) __hip_atomic_store(host_flag, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       return false;
     }
     __builtin_amdgcn_s_sleep(1);
@@ -1069,7 +1075,7 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
       bool alive = true;
       if (m == 0) {  // leader of group g
         unsigned v[kResMembers / 2];
-        alive = res_sweep<kResMembers / 2>(&xb->rows[g][0][0], tag, 2 * J, g, gridDim.x, true, v, &xb->abort_word);
+        alive = res_sweep<kResMembers / 2>(&xb->rows[g][0][0], tag, 2 * J, g, gridDim.x, true, v, &xb->abort_word, p.host_error);
         const double s = res_sum<kResMembers / 2>(v);
         if (lane < 2 * J && !(lane & 1u)) {
           const unsigned long long bits = __double_as_longlong(s);
@@ -1080,7 +1086,7 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
         }
       }
       unsigned v2[kResGroups / 2];
-      alive = res_sweep<kResGroups / 2>(&xb->sums[iters & 1u][0][0], tag, 2 * J, 0u, gridDim.x, false, v2, &xb->abort_word) && alive;
+      alive = res_sweep<kResGroups / 2>(&xb->sums[iters & 1u][0][0], tag, 2 * J, 0u, gridDim.x, false, v2, &xb->abort_word, p.host_error) && alive;
       const double s = res_sum<kResGroups / 2>(v2);
       if (lane < 2 * J && !(lane & 1u)) s_tot[lane >> 1] = s;
       if (lane == 0) s_alive = alive ? 1 : 0;
@@ -1166,12 +1172,16 @@ __global__ __launch_bounds__(BLOCK) void ts_flush(DevParams p, uint32_t par) {
 
 // Start of a schedule of n entries.  drop_pending: forget the pending gamma step
 // (tsamd_clear_pending).  n == 0xffffffff keeps the current schedule length.
-__global__ void ts_begin(DevParams p, const uint32_t *sched, uint32_t n, uint32_t par, uint32_t drop_pending) {
+__global__ void ts_begin(DevParams p, const uint32_t *host_sched, uint32_t *sched, uint32_t n, uint32_t par, uint32_t drop_pending) {
   Ctl *ctl = p.ctl;
   const uint32_t J = 2 * p.K;
   const State *S = &ctl->st[par ^ 1u];
   State *W = &ctl->st[par];
   if (p.xchg_world) publish_progress(p, S->epoch + 1ull);
+  // the schedule comes straight out of the caller's pinned staging buffer (no separate copy
+  // operation ahead of this kernel: one thing less between the call and the first pass)
+  if (n != 0xffffffffu && host_sched)
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) sched[i] = host_sched[i];
   carry_state(S, W, J);
   __syncthreads();
   if (threadIdx.x == 0) {
