@@ -1177,9 +1177,7 @@ static int sync_held_table(tsamd_ctx *c) {
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (total > c->held_cap) {
-    hipFree(c->res);
-  if (c->h_error) hipHostFree(c->h_error);
-  hipFree(c->d_hids);
+    hipFree(c->d_hids);
     hipFree(c->d_hy);
     hipFree(c->d_hterms);
     c->d_hids = nullptr, c->d_hy = nullptr, c->d_hterms = nullptr, c->held_cap = 0;
