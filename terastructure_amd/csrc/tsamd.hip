@@ -1038,7 +1038,8 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   const bool use_graph = graphs_allowed(c);
   if (use_graph)
     if (int rc = ensure_graphs(c)) return rc;
-  enqueue_begin(c, n, false, ent);  // (ts_begin copies the entries out of the pinned buffer itself)
+  HIP_TRY(c, hipMemcpyAsync(c->d_sched, ent, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  enqueue_begin(c, n, false);
   if (use_graph) {
     const uint32_t per_snp = kernels_per_snp(c);
     uint32_t left = n;

@@ -1178,8 +1178,8 @@ __global__ void ts_begin(DevParams p, const uint32_t *host_sched, uint32_t *sche
   const State *S = &ctl->st[par ^ 1u];
   State *W = &ctl->st[par];
   if (p.xchg_world) publish_progress(p, S->epoch + 1ull);
-  // the schedule comes straight out of the caller's pinned staging buffer (no separate copy
-  // operation ahead of this kernel: one thing less between the call and the first pass)
+  // (host_sched != NULL: take the entries straight from a pinned host buffer instead of a copy
+  // enqueued ahead of this kernel -- measured slower for short schedules, not used)
   if (n != 0xffffffffu && host_sched)
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) sched[i] = host_sched[i];
   carry_state(S, W, J);
