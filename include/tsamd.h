@@ -241,8 +241,19 @@ int tsamd_profile_read(tsamd_ctx *ctx, uint64_t *pass_launches, double *pass_ms_
 int tsamd_probe_stream(tsamd_ctx *ctx, uint32_t reps, double *read_us, double *rmw_us);
 /* how the context runs a SNP: kernels per SNP of the state-machine sequence (max_inner with one launch per
  * pass; 2 when all plain passes of a SNP run as one resident launch: single GPU, k <= 8, shards up to ~1M
- * individuals, TSAMD_RESIDENT=0 disables), workgroups of the plain-pass and first-pass kernels */
+ * individuals, TSAMD_RESIDENT=0 disables; 0 when a whole schedule runs as ONE launch with the weights kept in
+ * registers: the same conditions plus nodekappa == 0.5, TSAMD_PERSISTENT=0 disables), workgroups of the
+ * plain-pass and first-pass kernels */
 int tsamd_launch_info(tsamd_ctx *ctx, uint32_t *kernels_per_snp, uint32_t *plain_grid, uint32_t *first_grid);
+/* Selects how the context launches from now on: one kernel per pass, one resident kernel for the plain passes of
+ * a SNP, or one kernel per schedule.  tsamd_create picks the highest mode the context qualifies for; this call
+ * can lower it and raise it again (TSAMD_EUNSUPPORTED above what the context qualifies for).  All modes give the
+ * same results to rounding (the order in which the workgroups' partial rows are added differs), and each mode is
+ * bitwise reproducible and independent of how a schedule is cut into calls.  Synchronises the stream. */
+#define TSAMD_LAUNCH_PER_PASS 0
+#define TSAMD_LAUNCH_PER_SNP 1      /* first pass + ts_resident */
+#define TSAMD_LAUNCH_PER_SCHEDULE 2 /* ts_schedule */
+int tsamd_set_launch_mode(tsamd_ctx *ctx, int mode);
 /* device memory in bytes currently free / total on the context's device */
 int tsamd_mem_info(tsamd_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 

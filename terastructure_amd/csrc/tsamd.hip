@@ -112,7 +112,9 @@ struct tsamd_ctx {
   bool split = false;  // lambda_t leaves the pass via ctl->lt and the epilogue is its own kernel
   bool rccl_graph = false;  // TSAMD_RCCL_GRAPH=1: capture the RCCL all-reduce into the replayed graphs
   bool resident = false;    // plain passes of a SNP run as ONE launch (ts_resident) instead of max_inner - 1
-  ResXchg *res = nullptr;   // its in-launch exchange buffer
+  bool persistent = false;  // ... and a whole schedule runs as ONE launch (ts_schedule: the weights never leave the registers)
+  bool can_resident = false, can_persistent = false;  // what the context qualifies for (tsamd_set_launch_mode)
+  ResXchg *res = nullptr;   // their in-launch exchange buffer
   unsigned long long *h_error = nullptr;  // pinned: tag of a bounded in-kernel wait that gave up (0: none)
   // profiling
   bool prof = false;
@@ -163,12 +165,17 @@ int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
   void launch_k##k(int, uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, uint32_t); \
   int first_blocks_per_cu_k##k(int);                                                               \
   int resident_blocks_per_cu_k##k();
+#define TSAMD_SCHED_DECL(k)                                                                       \
+  void launch_schedule_k##k(uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t); \
+  int schedule_blocks_per_cu_k##k();
+#define TSAMD_SCHED_K(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #define TSAMD_ALL_K(X)                                                                             \
   X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)     \
   X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 }  // namespace
 namespace tsamd {
 TSAMD_ALL_K(TSAMD_DECL)
+TSAMD_SCHED_K(TSAMD_SCHED_DECL)  // tsamd_sched.hip, K <= kResidentMaxK
 }
 namespace {
 #define TSAMD_ENTRY(k) tsamd::launch_k##k,
@@ -177,6 +184,12 @@ const LaunchFn kLaunchers[TSAMD_SPECIALIZED_K + 1] = {nullptr, TSAMD_ALL_K(TSAMD
 int (*const kFirstBlocksPerCu[TSAMD_SPECIALIZED_K + 1])(int) = {nullptr, TSAMD_ALL_K(TSAMD_OCC_ENTRY)};
 #define TSAMD_RES_ENTRY(k) tsamd::resident_blocks_per_cu_k##k,
 int (*const kResidentBlocksPerCu[TSAMD_SPECIALIZED_K + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_RES_ENTRY)};
+static_assert(kResidentMaxK == 8, "TSAMD_SCHED_K lists K = 1 .. kResidentMaxK");
+typedef void (*ScheduleFn)(uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t);
+#define TSAMD_SCHED_ENTRY(k) tsamd::launch_schedule_k##k,
+const ScheduleFn kScheduleLaunchers[kResidentMaxK + 1] = {nullptr, TSAMD_SCHED_K(TSAMD_SCHED_ENTRY)};
+#define TSAMD_SCHED_OCC_ENTRY(k) tsamd::schedule_blocks_per_cu_k##k,
+int (*const kScheduleBlocksPerCu[kResidentMaxK + 1])() = {nullptr, TSAMD_SCHED_K(TSAMD_SCHED_OCC_ENTRY)};
 
 __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -294,6 +307,8 @@ void destroy_graph(tsamd_ctx *c) {
 
 // kernels of the state-machine sequence per SNP (ts_reduce_rows shares its pass' parity)
 uint32_t kernels_per_snp(const tsamd_ctx *c) { return c->resident ? 2u : c->cfg.max_inner; }
+// SNPs per ts_schedule launch at most (a launch of this many runs for seconds; every in-kernel wait is bounded)
+constexpr uint32_t kScheduleChunk = 1u << 16;
 
 // Capture 2^level consecutive SNP sequences for launch parity par0 on entry.  Kernels read
 // everything that varies (location, pending state) from device memory; the only frozen
@@ -409,7 +424,7 @@ void activate_xchg(tsamd_ctx *c) {
   c->p.xchg_test_delay = env_u32("TSAMD_TEST_XCHG_DELAY_US", 0) * 100u;  // test hooks (tsamd_device.h)
   c->p.xchg_test_noguard = env_u32("TSAMD_TEST_XCHG_NOGUARD", 0);
   c->split = true;
-  c->resident = false;
+  c->resident = c->persistent = c->can_resident = c->can_persistent = false;
   c->p2p = true;
   configure_launch(c, std::max<uint32_t>(16u, std::min<uint32_t>(kXchgBlocks, 512u / c->cfg.world)));
 }
@@ -610,10 +625,16 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
     // (at most eight items per thread of a 256-thread workgroup) and every workgroup can be resident at once.
     hipDeviceProp_t prop;
     const int cus = hipGetDeviceProperties(&prop, c->dev) == hipSuccess ? prop.multiProcessorCount : 0;
-    c->resident = !c->wide && !c->split && cfg->world == 1 && (int)cfg->k <= kResidentMaxK && c->block == 512u &&
+    c->resident = !c->wide && !c->split && cfg->world == 1 && (int)cfg->k <= kResidentMaxK &&
                   p.chunk <= (uint32_t)(kResidentItems * kResidentBlock) && (int)c->grid <= cus && c->grid <= (uint32_t)(kResGroups * kResMembers) &&
                   cfg->max_inner >= 2 && cfg->max_inner <= 200 && env_u32("TSAMD_RESIDENT", 1) != 0u &&
                   kResidentBlocksPerCu[cfg->k]() >= 1;
+    // ... and then, with the reference's default learning-rate exponent (the kernel carries no pow()), the whole
+    // schedule in one launch
+    c->persistent = c->resident && cfg->nodekappa == 0.5 && env_u32("TSAMD_PERSISTENT", 1) != 0u &&
+                    kScheduleBlocksPerCu[cfg->k]() >= 1;
+    c->can_resident = c->resident;
+    c->can_persistent = c->persistent;
   }
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
@@ -1039,6 +1060,28 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   if (use_graph)
     if (int rc = ensure_graphs(c)) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_sched, ent, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  if (c->persistent) {
+    // one launch runs the whole schedule (in pieces of kScheduleChunk SNPs): it starts from the State the
+    // previous call left and leaves one like ts_flush does -- no ts_begin, no ts_flush
+    for (uint32_t off = 0; off < n; off += kScheduleChunk) {
+      const uint32_t len = std::min(kScheduleChunk, n - off);
+      const bool prof = c->prof && c->n_ev_pass < kProfCap;
+      if (c->prof && !prof) c->prof_capped = true;
+      hipEvent_t e = nullptr;
+      if (prof) {
+        if (int rc = prof_event(c, c->ev_pass, 2 * c->n_ev_pass, &e)) return rc;
+        HIP_TRY(c, hipEventRecord(e, c->stream));
+      }
+      kScheduleLaunchers[c->cfg.k](c->grid, c->stream, c->p, next_parity(c), c->d_sched + off, len);
+      if (prof) {
+        if (int rc = prof_event(c, c->ev_pass, 2 * c->n_ev_pass + 1, &e)) return rc;
+        HIP_TRY(c, hipEventRecord(e, c->stream));
+        c->n_ev_pass++;
+      }
+    }
+    HIP_TRY(c, hipGetLastError());
+    return TSAMD_OK;
+  }
   enqueue_begin(c, n, false);
   if (use_graph) {
     const uint32_t per_snp = kernels_per_snp(c);
@@ -1072,6 +1115,12 @@ int tsamd_prepare(tsamd_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->dev));
   if (c->cfg.world > 1 && !c->comm && !c->p2p) return TSAMD_OK;  // exchange not chosen yet: nothing to capture
+  if (c->persistent) {  // an empty schedule: the kernel's code object is loaded, the state only carried forward
+    kScheduleLaunchers[c->cfg.k](c->grid, c->stream, c->p, next_parity(c), c->d_sched, 0u);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return TSAMD_OK;
+  }
   if (!graphs_allowed(c)) return TSAMD_OK;
   if (int rc = ensure_graphs(c)) return rc;
   // One dry replay of every graph: whatever the runtime does on a graph's first launch happens
@@ -1098,15 +1147,17 @@ int tsamd_synchronize(tsamd_ctx *c) {
   if (c->h_error && *(volatile unsigned long long *)c->h_error != 0ull) {  // (written by the kernel that gave up)
     const unsigned long long err = *(volatile unsigned long long *)c->h_error;
     if (c->p2p) return fail(c, TSAMD_ECOMM, "peer-to-peer exchange timed out waiting for a peer (epoch %llu)", err);
-    return fail(c, TSAMD_EHIP, "resident pass kernel: the in-launch exchange timed out (tag %llu): are all %u workgroups "
-                "resident?  TSAMD_RESIDENT=0 selects one launch per pass", err, c->grid);
+    return fail(c, TSAMD_EHIP, "%s: the in-launch exchange timed out (tag %llu): are all %u workgroups resident?  "
+                "TSAMD_PERSISTENT=0 selects one launch per SNP for the plain passes, TSAMD_RESIDENT=0 one launch per pass",
+                c->persistent ? "ts_schedule" : "ts_resident", err, c->grid);
   }
   if (c->prof) {
     for (uint32_t i = 0; i < c->n_ev_pass; ++i) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, c->ev_pass[2 * i], c->ev_pass[2 * i + 1]) == hipSuccess) {
         c->prof_pass_ms += ms;
-        c->prof_pass_n += c->cfg.max_inner - 1;  // launches inside the bracket (profile_read corrects for no-ops)
+        // launches inside the bracket (profile_read corrects for no-ops); ts_schedule: the bracket is one launch
+        c->prof_pass_n += c->persistent ? 1u : c->cfg.max_inner - 1;
       }
     }
     for (uint32_t i = 0; i < c->n_ev_first; ++i) {
@@ -1280,7 +1331,7 @@ int tsamd_comm_init(tsamd_ctx *c, const uint8_t id[TSAMD_COMM_ID_BYTES]) {
     return fail(c, TSAMD_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
   }
   c->split = true;
-  c->resident = false;
+  c->resident = c->persistent = c->can_resident = c->can_persistent = false;
   c->p.rows_from_lt = 1u;
   c->rccl_graph = env_u32("TSAMD_RCCL_GRAPH", 0) != 0u;
   destroy_graph(c);
@@ -1440,7 +1491,7 @@ int tsamd_profile_read(tsamd_ctx *c, uint64_t *pass_launches, double *pass_ms_to
   // plain passes that really swept: the passes the device counted since profiling was enabled
   // minus the first passes (a SNP that converges early leaves near-empty launches inside its
   // bracket; dividing by them would overstate the rate)
-  if (!c->prof_capped && c->prof_first_n) {
+  if (!c->prof_capped && c->prof_first_n && !c->persistent) {
     unsigned long long v = 0;
     HIP_TRY(c, hipMemcpy(&v, &c->p.ctl->total_passes, sizeof v, hipMemcpyDeviceToHost));
     const uint64_t ran = v - c->prof_passes0;
@@ -1492,9 +1543,23 @@ int tsamd_probe_stream(tsamd_ctx *c, uint32_t reps, double *read_us, double *rmw
 
 int tsamd_launch_info(tsamd_ctx *c, uint32_t *kernels_per_snp_out, uint32_t *plain_grid, uint32_t *first_grid) {
   CHECK_CTX(c);
-  if (kernels_per_snp_out) *kernels_per_snp_out = kernels_per_snp(c);
+  if (kernels_per_snp_out) *kernels_per_snp_out = c->persistent ? 0u : kernels_per_snp(c);
   if (plain_grid) *plain_grid = c->grid;
   if (first_grid) *first_grid = c->grid_first;
+  return TSAMD_OK;
+}
+
+int tsamd_set_launch_mode(tsamd_ctx *c, int mode) {
+  CHECK_CTX(c);
+  if (mode < TSAMD_LAUNCH_PER_PASS || mode > TSAMD_LAUNCH_PER_SCHEDULE) return fail(c, TSAMD_EINVAL, "launch mode %d", mode);
+  if ((mode >= TSAMD_LAUNCH_PER_SNP && !c->can_resident) || (mode == TSAMD_LAUNCH_PER_SCHEDULE && !c->can_persistent))
+    return fail(c, TSAMD_EUNSUPPORTED, "launch mode %d needs one GPU, k <= %d, a shard that fits the register file%s", mode,
+                kResidentMaxK, mode == TSAMD_LAUNCH_PER_SCHEDULE ? " and nodekappa == 0.5" : "");
+  if (int rc = tsamd_synchronize(c)) return rc;
+  const bool resident = mode >= TSAMD_LAUNCH_PER_SNP, persistent = mode == TSAMD_LAUNCH_PER_SCHEDULE;
+  if (resident != c->resident) destroy_graph(c);  // (captured for the other kernel sequence)
+  c->resident = resident;
+  c->persistent = persistent;
   return TSAMD_OK;
 }
 

@@ -54,6 +54,8 @@ struct Ctl {
                          // argument of the pass kernels, so captured graphs survive a reallocation
   uint32_t sched_len;   // entries in the schedule; kernels past the end only carry state forward
   uint32_t last_iters;  // inner passes of the most recently completed SNP (for tsamd_snp_update)
+  uint32_t xseq;        // in-launch exchanges done so far (ts_resident / ts_schedule: the tag of the next one is xseq + 1)
+  uint32_t pad_;
   unsigned long long total_passes;
   unsigned long long pass_hist[TSAMD_PASS_HIST_BINS];  // completed SNPs by inner passes run (last bin: that many or more)
   State st[2];

@@ -870,10 +870,9 @@ constexpr int kResidentBlock = 256;
 template <int N>
 __device__ __forceinline__ bool res_sweep(const unsigned long long *base, uint32_t tag, uint32_t nvalid_gran, uint32_t group,
                                           uint32_t grid, bool by_member, unsigned (&v)[N], unsigned long long *abort_word,
-                                          unsigned long long *host_flag) {
+                                          unsigned long long *host_flag, uint32_t lane) {
   // lane l, load i: granule c = l % 32 of row 2 i + (l >= 32); a row is a member's (level 1: it
   // exists if member * 8 + group < grid) or a group's (level 2: group index < min(grid, 8))
-  const uint32_t lane = threadIdx.x & 63u;
   const uint32_t c = lane & 31u;
   const unsigned long long t0 = wall_clock64();
   for (;;) {
@@ -902,8 +901,7 @@ __device__ __forceinline__ bool res_sweep(const unsigned long long *base, uint32
 // sum of the N rows a wave has swept (lo / hi halves of a double sit in neighbouring lanes): on
 // return lane 2 j (j < J) holds the total of value j over rows 0, 2, 4, ... plus rows 1, 3, 5, ...
 template <int N>
-__device__ __forceinline__ double res_sum(const unsigned (&v)[N]) {
-  const uint32_t lane = threadIdx.x & 63u;
+__device__ __forceinline__ double res_sum(const unsigned (&v)[N], uint32_t lane) {
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -935,6 +933,7 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
   State *W = &ctl->st[par];
   const uint32_t sidx = S->idx, svalid = S->valid, sdone = S->done, sloc = S->loc, shol = S->hol;
   const uint32_t siters = S->iters, snrows = S->nrows;
+  const uint32_t xseq0 = ctl->xseq;  // (workgroup 0 advances it when it leaves, after everybody's first exchange)
   __builtin_amdgcn_sched_barrier(0);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const size_t np = npad_a;
@@ -1017,6 +1016,7 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
   };
   // end of a pass: workgroup reduction; then either (the cap) hand rows and state to the next launch,
   // or exchange the rows inside the launch and run the epilogue.  Returns true when the kernel is over.
+  uint32_t xcount = 0u;  // exchanges of this launch
   auto finish_pass = [&]() -> bool {
     {
       using Fold = WaveFold<2 * KT>;  // fixed order: lanes (halving butterfly) -> waves
@@ -1058,12 +1058,14 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
           W->done = 0u;
           W->nrows = gridDim.x;
           W->epoch = epoch_now;
+          ctl->xseq = xseq0 + xcount;
         }
       }
       return true;
     }
     // ---- in-launch exchange of the partial rows ---------------------------------------------
-    const uint32_t tag = (uint32_t)(epoch_now << 8) + iters;
+    xcount += 1u;
+    const uint32_t tag = xseq0 + xcount;
     if (tid < J) {
       const unsigned long long bits = __double_as_longlong(row);
       __hip_atomic_store(&xb->rows[g][m][2 * tid], ((unsigned long long)tag << 32) | (uint32_t)bits, __ATOMIC_RELAXED,
@@ -1075,19 +1077,19 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
       bool alive = true;
       if (m == 0) {  // leader of group g
         unsigned v[kResMembers / 2];
-        alive = res_sweep<kResMembers / 2>(&xb->rows[g][0][0], tag, 2 * J, g, gridDim.x, true, v, &xb->abort_word, p.host_error);
-        const double s = res_sum<kResMembers / 2>(v);
+        alive = res_sweep<kResMembers / 2>(&xb->rows[g][0][0], tag, 2 * J, g, gridDim.x, true, v, &xb->abort_word, p.host_error, lane);
+        const double s = res_sum<kResMembers / 2>(v, lane);
         if (lane < 2 * J && !(lane & 1u)) {
           const unsigned long long bits = __double_as_longlong(s);
-          __hip_atomic_store(&xb->sums[iters & 1u][g][lane], ((unsigned long long)tag << 32) | (uint32_t)bits, __ATOMIC_RELAXED,
+          __hip_atomic_store(&xb->sums[tag & 1u][g][lane], ((unsigned long long)tag << 32) | (uint32_t)bits, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&xb->sums[iters & 1u][g][lane + 1], ((unsigned long long)tag << 32) | (uint32_t)(bits >> 32),
+          __hip_atomic_store(&xb->sums[tag & 1u][g][lane + 1], ((unsigned long long)tag << 32) | (uint32_t)(bits >> 32),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       unsigned v2[kResGroups / 2];
-      alive = res_sweep<kResGroups / 2>(&xb->sums[iters & 1u][0][0], tag, 2 * J, 0u, gridDim.x, false, v2, &xb->abort_word, p.host_error) && alive;
-      const double s = res_sum<kResGroups / 2>(v2);
+      alive = res_sweep<kResGroups / 2>(&xb->sums[tag & 1u][0][0], tag, 2 * J, 0u, gridDim.x, false, v2, &xb->abort_word, p.host_error, lane) && alive;
+      const double s = res_sum<kResGroups / 2>(v2, lane);
       if (lane < 2 * J && !(lane & 1u)) s_tot[lane >> 1] = s;
       if (lane == 0) s_alive = alive ? 1 : 0;
     }
@@ -1099,7 +1101,10 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
     return false;
   };
   auto publish = [&]() {
-    if (blockIdx.x == 0) publish_complete_v(p, ctl, W, J, sidx, sloc, shol, iters, epoch_now, eb_used, s_lam, s_eb);
+    if (blockIdx.x == 0) {
+      publish_complete_v(p, ctl, W, J, sidx, sloc, shol, iters, epoch_now, eb_used, s_lam, s_eb);
+      if (tid == 0) ctl->xseq = xseq0 + xcount;
+    }
   };
 
   if (complete) {  // (the first pass was the SNP's last)
@@ -1133,6 +1138,422 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
     }
     if (finish_pass()) return;
   }
+}
+
+
+// ---------------------------------------------------------------------------
+// ts_schedule<K>: a WHOLE schedule in one launch (single GPU, K <= 8, shards up to ~1M individuals:
+// same residency conditions as ts_resident).  The weights w stay in registers from the first SNP
+// to the last: the gamma step of a SNP reads and writes gamma (and c_n) only and overwrites the
+// registers with the new weights, every pass runs from registers, and every pass ends with the
+// in-launch exchange of the partial rows (ResXchg).  Per SNP the memory traffic drops from
+// (I + 3) 8NK to 16NK (gamma read + write); w is written back once, at the end of the launch.
+// Same semantics as the launch-per-pass state machine: starts from the State the previous call
+// left (its last SNP complete, its gamma step possibly pending) and leaves such a State.
+template <int KT>
+__global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
+                                                      const uint32_t *sched, uint32_t n_sched, ResXchg *xb, const DevParams p) {
+  constexpr int BLOCK = 256, kWaves = BLOCK / 64, kItems = kResidentItems;
+  using WT = double2;
+  constexpr uint32_t kItemsPerWord = 8u, kCodeBits = 4u;
+  constexpr uint32_t J = 2 * KT;
+  __shared__ double s_eb[J], s_lam[J], s_diff[J], s_tot[J], s_sb[J], s_plam[J], s_peb[J];
+  __shared__ double s_red[kWaves][J];
+  __shared__ int s_alive;
+  const uint32_t par = par_arg & 1u;
+  Ctl *ctl = ctl_a;
+  const State *S = &ctl->st[par ^ 1u];
+  State *W = &ctl->st[par];
+  const uint32_t svalid = S->valid, sloc = S->loc, shol = S->hol, siters = S->iters, sidx = S->idx;
+  const unsigned long long epoch_now = S->epoch + 1ull;
+  const uint32_t xseq0 = ctl->xseq;  // (workgroup 0 advances it when it leaves, after everybody's first exchange)
+  uint32_t tid = threadIdx.x;
+  const size_t np = npad_a;
+  const uint32_t nitems = npad_a / 2u;
+  const uint32_t begin = blockIdx.x * chunk_a, end = min(begin + chunk_a, nitems);
+  uint32_t i0 = begin + tid;
+  uint32_t cnt = (i0 < end) ? min((end - i0 + BLOCK - 1u) / BLOCK, (uint32_t)kItems) : 0u;
+  // Everything below sits in one loop over the schedule with the sweeps fully unrolled: left alone, the
+  // compiler hoists every address that depends only on (thread, item, row) out of that loop -- a few
+  // hundred values, spilled -- so the three values they derive from are made opaque per use.
+  auto fresh = [&]() { asm volatile("" : "+v"(tid), "+v"(i0), "+v"(cnt)); };
+  auto item_or_last = [&](uint32_t t) { return cnt ? i0 + min(t, cnt - 1u) * BLOCK : min(i0, nitems - 1u); };
+  const uint32_t g = blockIdx.x % (uint32_t)kResGroups, m = blockIdx.x / (uint32_t)kResGroups;
+
+  if (n_sched == 0u) {
+    if (blockIdx.x == 0) carry_state(S, W, J);
+    return;
+  }
+  // the shard's weights: loaded once (two items in flight at a time), kept for the whole launch
+  WT buf[kItems][KT];
+#pragma unroll
+  for (int t = 0; t < kItems; ++t) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) buf[t][k] = reinterpret_cast<const WT *>(w_a + (size_t)k * np)[item_or_last((uint32_t)t)];
+    if (t & 1) __builtin_amdgcn_sched_barrier(0);
+  }
+  auto get_item = [&](int t, WT (&wv)[KT]) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) wv[k] = buf[t][k];
+  };
+  auto put_item = [&](int t, const WT (&wv)[KT]) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) buf[t][k] = wv[k];
+  };
+  // the previous call's last SNP: its gamma step may be pending (column bits, exp(Elogbeta) of its last
+  // pass), and its final values serve a first SNP at the same location
+  uint32_t pword[kItems];
+  {
+    const uint32_t *pcol = reinterpret_cast<const uint32_t *>(p.bed + (size_t)sloc * p.colstride);
+#pragma unroll
+    for (int t = 0; t < kItems; ++t) pword[t] = svalid ? pcol[item_or_last((uint32_t)t) / kItemsPerWord] : 0x55555555u;
+  }
+  if (tid < J) {
+    s_sb[tid] = S->eb[tid];
+    s_plam[tid] = svalid ? p.lam[(size_t)sloc * J + tid] : 0.0;
+    s_peb[tid] = svalid ? p.eb[(size_t)sloc * J + tid] : 0.0;
+  }
+  bool do_gamma = svalid != 0u && shol == 0u;
+  bool prev_valid = svalid != 0u;
+  uint32_t prev_loc = sloc, prev_hol = shol, prev_iters = siters;
+  bool w_dirty = false;
+  uint32_t xcount = 0u;  // exchanges of this launch
+#ifdef TSAMD_SCHED_TIME  // diagnostic build (tools/variant.sh): where a SNP's time goes, 10 ns ticks, workgroup 0
+  unsigned long long tk_gamma = 0, tk_first = 0, tk_rest = 0, tk_xchg = 0, tk_head = 0, tk_tail = 0, tk_mark = wall_clock64();
+  const unsigned long long tk_start = tk_mark;
+#define TSAMD_TK(acc)                         \
+  do {                                        \
+    const unsigned long long now_ = wall_clock64(); \
+    acc += now_ - tk_mark;                    \
+    tk_mark = now_;                           \
+  } while (0)
+#else
+#define TSAMD_TK(acc) \
+  do {                \
+  } while (0)
+#endif
+  __syncthreads();
+
+  uint32_t iters = 0u;
+  double lam_old = 0.0, eb_used = 0.0;
+  double b0[KT], b1[KT], acc0[KT], acc1[KT];
+  bool complete = false;
+  auto begin_pass = [&]() {
+    fresh();
+    iters += 1u;
+    lam_old = s_lam[tid < J ? tid : 0u];
+    eb_used = s_eb[tid < J ? tid : 0u];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      b0[k] = uniform_f64(s_eb[2 * k]);
+      b1[k] = uniform_f64(s_eb[2 * k + 1]);
+      acc0[k] = acc1[k] = 0.0;
+    }
+  };
+  auto consume = [&](uint32_t i, const WT (&wv)[KT], uint32_t wd) {
+    const uint32_t code = wd >> (kCodeBits * (i % kItemsPerWord));
+    double c0[2], c1[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      double mom, dad;
+      bool ok;
+      code_weights((code >> (2 * v)) & 3u, mom, dad, ok);
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const double wk = v ? wv[k].y : wv[k].x;
+        s0 = fma(wk, b0[k], s0);
+        s1 = fma(wk, b1[k], s1);
+      }
+      c0[v] = mom * fast_rcp(s0);
+      c1[v] = dad * fast_rcp(s1);
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      acc0[k] = fma(c0[1], wv[k].y, acc0[k]);
+      acc1[k] = fma(c1[1], wv[k].y, acc1[k]);
+      acc0[k] = fma(c0[0], wv[k].x, acc0[k]);
+      acc1[k] = fma(c1[0], wv[k].x, acc1[k]);
+    }
+  };
+  // end of a pass: workgroup reduction, in-launch exchange, epilogue.  false: the exchange gave up.
+  auto finish_pass = [&]() -> bool {
+    fresh();
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    {
+      using Fold = WaveFold<2 * KT>;
+      double v[Fold::P];
+#pragma unroll
+      for (int q = 0; q < Fold::P; ++q) v[q] = 0.0;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        v[2 * k] = acc0[k];
+        v[2 * k + 1] = acc1[k];
+      }
+      const double tot = Fold::fold(v, lane);
+      const int slot = Fold::slot(lane);
+      constexpr uint32_t kRep = 64 / Fold::P;
+      if ((lane & (kRep - 1u)) == 0u && slot < (int)J) s_red[wave][slot] = tot;
+    }
+    __syncthreads();
+#ifdef TSAMD_SCHED_TIME
+    const unsigned long long tx0 = wall_clock64();
+#endif
+    xcount += 1u;
+    const uint32_t tag = xseq0 + xcount;
+    if (tid < J) {
+      double row = s_red[0][tid];
+#pragma unroll
+      for (int wv = 1; wv < kWaves; ++wv) row += s_red[wv][tid];
+      const unsigned long long bits = __double_as_longlong(row);
+      __hip_atomic_store(&xb->rows[g][m][2 * tid], ((unsigned long long)tag << 32) | (uint32_t)bits, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&xb->rows[g][m][2 * tid + 1], ((unsigned long long)tag << 32) | (uint32_t)(bits >> 32), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave == 0) {
+      bool alive = true;
+      if (m == 0) {
+        unsigned v[kResMembers / 2];
+        alive = res_sweep<kResMembers / 2>(&xb->rows[g][0][0], tag, 2 * J, g, gridDim.x, true, v, &xb->abort_word, p.host_error, lane);
+        const double s = res_sum<kResMembers / 2>(v, lane);
+        if (lane < 2 * J && !(lane & 1u)) {
+          const unsigned long long bits = __double_as_longlong(s);
+          __hip_atomic_store(&xb->sums[tag & 1u][g][lane], ((unsigned long long)tag << 32) | (uint32_t)bits, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&xb->sums[tag & 1u][g][lane + 1], ((unsigned long long)tag << 32) | (uint32_t)(bits >> 32),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      unsigned v2[kResGroups / 2];
+      alive = res_sweep<kResGroups / 2>(&xb->sums[tag & 1u][0][0], tag, 2 * J, 0u, gridDim.x, false, v2, &xb->abort_word,
+                                        p.host_error, lane) && alive;
+      const double s = res_sum<kResGroups / 2>(v2, lane);
+      if (lane < 2 * J && !(lane & 1u)) s_tot[lane >> 1] = s;
+      if (lane == 0) s_alive = alive ? 1 : 0;
+    }
+    __syncthreads();
+#ifdef TSAMD_SCHED_TIME
+    tk_xchg += wall_clock64() - tx0;
+#endif
+    if (!s_alive) return false;
+    if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);
+    __syncthreads();
+    complete = epilogue_complete(p, iters, J, s_diff);
+    return true;
+  };
+
+  // The next SNP's entry and its location's lambda / exp(Elogbeta) are requested one SNP ahead (after the
+  // current SNP's first exchange: workgroup 0 has then published every earlier SNP of this launch with
+  // agent-scope stores); a SNP at the location of its predecessor takes that one's final values from LDS.
+  uint32_t loc = 0, hol = 0;
+  uint32_t ent_n = sched[0];
+  double nlam = 0.0, neb = 0.0;
+  if (tid < J) {
+    nlam = p.lam[(size_t)(ent_n & 0x7fffffffu) * J + tid];
+    neb = p.eb[(size_t)(ent_n & 0x7fffffffu) * J + tid];
+  }
+  for (uint32_t idx = 0; idx < n_sched; ++idx) {
+    const uint32_t ent = ent_n;
+    loc = ent & 0x7fffffffu;
+    hol = ent >> 31;
+    ent_n = sched[min(idx + 1u, n_sched - 1u)];
+    if (tid < J) {
+      const bool local = prev_valid && loc == prev_loc;
+      s_lam[tid] = local ? s_plam[tid] : nlam;
+      s_eb[tid] = local ? s_peb[tid] : neb;
+    }
+    fresh();
+    uint32_t word[kItems];
+    {
+      const uint32_t *col = reinterpret_cast<const uint32_t *>(p.bed + (size_t)loc * p.colstride);
+#pragma unroll
+      for (int t = 0; t < kItems; ++t) word[t] = col[item_or_last((uint32_t)t) / kItemsPerWord];
+    }
+    __syncthreads();
+    iters = 0u;
+    TSAMD_TK(tk_head);
+    // ---- the previous SNP's gamma step (phi from the resident weights and the exp(Elogbeta) of that
+    // SNP's last pass, read from LDS at each use).  Straight-line per item: an item past the end of the
+    // thread's range is processed with "missing" codes and only its stores are guarded; an unobserved
+    // genotype computes and discards (selects, no branch around assignments to the resident weights).
+    if (do_gamma) {
+      WT gv[KT], gv_n[KT];
+      uint2 cv, cv_n;
+      auto load_gamma = [&](uint32_t i, WT (&gq)[KT], uint2 &cq) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) gq[k] = reinterpret_cast<const WT *>(p.gam + (size_t)k * np)[i];
+        cq = reinterpret_cast<const uint2 *>(p.cnt)[i];
+      };
+      load_gamma(item_or_last(0), gv, cv);
+#pragma unroll
+      for (int t = 0; t < kItems; ++t) {
+        fresh();
+        const uint32_t i = item_or_last((uint32_t)t);
+        const bool mine = (uint32_t)t < cnt;
+        load_gamma(item_or_last((uint32_t)t + 1u), gv_n, cv_n);  // (clamped: the last one is a harmless re-read)
+        __builtin_amdgcn_sched_barrier(0);
+        WT wcur[KT];
+        get_item(t, wcur);
+        uint32_t pcode = mine ? pword[t] >> (kCodeBits * (i % kItemsPerWord)) : 0x5u;
+        // the item's two individuals, one after the other through ONE copy of the code (a rolled loop that
+        // works on the .x halves and swaps the halves after each turn: eight items times two individuals of
+        // straight-line digamma / exp code would not fit the instruction cache)
+#pragma unroll 1
+        for (int v = 0; v < 2; ++v) {
+          double mom, dad;
+          bool ok;
+          code_weights(pcode & 3u, mom, dad, ok);
+          pcode >>= 2;
+          double gx[KT], wx[KT];
+          double s0 = 0.0, s1 = 0.0;
+          uint32_t zo = 0u;  // (opaque zero: exp(Elogbeta) is re-read from LDS where it is used, not held in 32 registers)
+          asm volatile("" : "+v"(zo));
+          const double *sbv = s_sb + zo;
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            gx[k] = gv[k].x;
+            wx[k] = wcur[k].x;
+            s0 = fma(wx[k], sbv[2 * k], s0);
+            s1 = fma(wx[k], sbv[2 * k + 1], s1);
+          }
+          // update_gamma + update_rho_indiv (src/snpsamplinge.cc:688-719), as gamma_step_one with nodekappa = 0.5
+          // (the host selects this kernel only then)
+          const double rho = 1.0 / sqrt(p.nodetau0 + (double)cv.x);
+          const double c0 = mom * fast_rcp(s0), c1 = dad * fast_rcp(s1);
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            const double e = c0 * (wx[k] * sbv[2 * k]) + c1 * (wx[k] * sbv[2 * k + 1]);
+            gx[k] += rho * (p.alpha + p.gamma_scale * e - gx[k]);
+          }
+          gamma_to_w<KT>(gx, wx);
+          const uint32_t cnew = ok ? cv.x + 1u : cv.x;
+          cv.x = cv.y;
+          cv.y = cnew;
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            const double gnew = ok ? gx[k] : gv[k].x, wnew = ok ? wx[k] : wcur[k].x;
+            gv[k].x = gv[k].y;
+            gv[k].y = gnew;
+            wcur[k].x = wcur[k].y;
+            wcur[k].y = wnew;
+          }
+        }
+        if (mine) {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = gv[k];
+          reinterpret_cast<uint2 *>(p.cnt)[i] = cv;
+        }
+        put_item(t, wcur);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) gv[k] = gv_n[k];
+        cv = cv_n;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      w_dirty = true;
+    }
+    TSAMD_TK(tk_gamma);
+    // ---- first pass of the new SNP, from the resident weights like every later one --------------------
+    begin_pass();
+#pragma unroll
+    for (int t = 0; t < kItems; ++t) {
+      fresh();
+      WT wcur[KT];
+      get_item(t, wcur);
+      consume(item_or_last((uint32_t)t), wcur, (uint32_t)t < cnt ? word[t] : 0x55555555u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!finish_pass()) return;
+    TSAMD_TK(tk_first);
+    fresh();
+    if (tid < J) {
+      nlam = __hip_atomic_load(&p.lam[(size_t)(ent_n & 0x7fffffffu) * J + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      neb = __hip_atomic_load(&p.eb[(size_t)(ent_n & 0x7fffffffu) * J + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    while (!complete) {
+      begin_pass();
+#pragma unroll
+      for (int t = 0; t < kItems; ++t) {
+        fresh();
+        WT wcur[KT];
+        get_item(t, wcur);
+        consume(item_or_last((uint32_t)t), wcur, (uint32_t)t < cnt ? word[t] : 0x55555555u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!finish_pass()) return;
+    }
+    TSAMD_TK(tk_rest);
+    // ---- the SNP is complete: s_lam / s_eb hold its final values, eb_used the exp(Elogbeta) its last
+    // pass used.  Workgroup 0 publishes; everybody keeps what the next SNP's gamma step needs.
+    if (blockIdx.x == 0) {
+      if (tid < J) {
+        __hip_atomic_store(&p.lam[(size_t)loc * J + tid], s_lam[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.eb[(size_t)loc * J + tid], s_eb[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (tid == 0) {
+        ctl->last_iters = iters;
+        ctl->total_passes += (unsigned long long)iters;
+        ctl->pass_hist[min(iters, (uint32_t)TSAMD_PASS_HIST_BINS - 1u)] += 1ull;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // published before this workgroup joins the next exchange
+    }
+    __syncthreads();
+    if (tid < J) {
+      s_sb[tid] = eb_used;
+      s_plam[tid] = s_lam[tid];
+      s_peb[tid] = s_eb[tid];
+    }
+#pragma unroll
+    for (int t = 0; t < kItems; ++t) pword[t] = word[t];
+    do_gamma = hol == 0u;
+    prev_valid = true;
+    prev_loc = loc;
+    prev_hol = hol;
+    prev_iters = iters;
+    __syncthreads();
+    TSAMD_TK(tk_tail);
+  }
+
+  // ---- end of the launch: the weights go back to memory, the state to the next call -------------
+  if (w_dirty) {
+#pragma unroll
+    for (int t = 0; t < kItems; ++t) {
+      fresh();
+      if ((uint32_t)t < cnt) {
+        const uint32_t i = i0 + (uint32_t)t * BLOCK;
+        WT wcur[KT];
+        get_item(t, wcur);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(w_a + (size_t)k * np)[i] = wcur[k];
+      }
+    }
+  }
+  fresh();
+  if (blockIdx.x == 0) {
+    if (tid < J) {
+      W->lam[tid] = s_plam[tid];
+      W->eb[tid] = s_sb[tid];
+    }
+    if (tid == 0) {
+      W->idx = sidx + n_sched;
+      W->valid = 1u;
+      W->loc = prev_loc;
+      W->hol = prev_hol;
+      W->iters = prev_iters;
+      W->done = 1u;
+      W->nrows = 0u;
+      W->epoch = epoch_now;
+      ctl->xseq = xseq0 + xcount;
+#ifdef TSAMD_SCHED_TIME
+      if (n_sched > 100u)
+        printf("ts_schedule n=%u exchanges=%u | per SNP (us): head %.2f gamma %.2f first pass %.2f later passes %.2f tail %.2f | "
+               "in exchanges %.2f | whole launch %.1f us\n", n_sched, xcount, tk_head * 0.01 / n_sched, tk_gamma * 0.01 / n_sched,
+               tk_first * 0.01 / n_sched, tk_rest * 0.01 / n_sched, tk_tail * 0.01 / n_sched, tk_xchg * 0.01 / n_sched,
+               (wall_clock64() - tk_start) * 0.01);
+#endif
+    }
+  }
+#undef TSAMD_TK
 }
 
 #ifdef TSAMD_MAIN_TU  // K-independent kernels: compiled into tsamd.hip only

@@ -293,6 +293,10 @@ class Engine:
         self._check(self.h.tsamd_launch_info(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
         return dict(kernels_per_snp=a.value, plain_grid=b.value, first_grid=c.value)
 
+    def set_launch_mode(self, mode):
+        """LAUNCH_PER_PASS / LAUNCH_PER_SNP / LAUNCH_PER_SCHEDULE -- tsamd_set_launch_mode"""
+        self._check(self.h.tsamd_set_launch_mode(self.ctx, int(mode)))
+
     def mem_info(self):
         f, t = C.c_uint64(0), C.c_uint64(0)
         self._check(self.h.tsamd_mem_info(self.ctx, C.byref(f), C.byref(t)))
