@@ -324,40 +324,63 @@ def main():
     # once and keeps them in registers: its algorithmic bytes per launch are passes x the plain-pass bytes.
     roofline = None
     if not args.no_profile:
-        prof_steps = min(args.steps, 300)
         info = eng.launch_info()
-        resident = info["kernels_per_snp"] == 2 and eng.cfg.max_inner > 2
-        eng.profile_enable(True)
-        eng.run_schedule(locs[args.warmup:args.warmup + prof_steps])
-        eng.synchronize()
-        pr = eng.profile_read()
-        eng.profile_enable(False)
-        if pr["pass_launches"]:
-            pass_bytes = 8.0 * sc * k + sc / 4.0
-            first_s = pr["first_ms"] / max(1, pr["first_launches"]) * 1e-3
-            first_bytes = 32.0 * sc * k + 8.0 * sc + sc / 2.0
+        kps = info["kernels_per_snp"]
+        mode = "schedule" if kps == 0 else "snp" if (kps == 2 and eng.cfg.max_inner > 2) else "pass"
+        pass_bytes = 8.0 * sc * k + sc / 4.0
+        first_bytes = 32.0 * sc * k + 8.0 * sc + sc / 2.0
+
+        def pmc_record(want):
+            pmc = os.path.join(ROOT, "profiles", "pass_kernel_pmc.json")
+            try:
+                for rec in json.load(open(pmc)).get("records", []):
+                    if rec.get("n") == n and rec.get("k") == k and rec.get("n_gpus") == world and rec.get("mode", "pass") == want:
+                        return rec
+            except Exception:  # noqa: BLE001
+                pass
+            return {}
+
+        def profiled(nsteps):
+            """(profile_read dict, passes the device ran) over nsteps updates"""
+            eng.synchronize()
+            q0 = eng.total_passes()
+            eng.profile_enable(True)
+            eng.run_schedule(locs[args.warmup:args.warmup + nsteps])
+            eng.synchronize()
+            pr_ = eng.profile_read()
+            eng.profile_enable(False)
+            return pr_, eng.total_passes() - q0
+
+        try:
+            read_us, rmw_us = eng.probe_stream(50)
+        except Exception as exc:  # noqa: BLE001 -- an extra, never fatal
+            read_us = rmw_us = None
+            print(f"[bench] stream probe skipped: {exc}", file=sys.stderr, flush=True)
+
+        # the kernels of the launch-per-SNP / launch-per-pass sequence (the default mode for K > 8, sharded runs and
+        # shards beyond ~1M individuals; with the whole-schedule kernel they are timed in LAUNCH_PER_SNP mode, switched
+        # to for this measurement only)
+        per_snp = None
+        if mode == "schedule":
+            eng.set_launch_mode(ts.LAUNCH_PER_SNP)
+            try:
+                pr, _ = profiled(min(args.steps, 300))
+            finally:
+                eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+            sub_mode = "snp" if eng.cfg.max_inner > 2 else "pass"
+        else:
+            pr, _ = profiled(min(args.steps, 300))
+            sub_mode = mode
+        if pr["pass_launches"] and pr["first_launches"]:
+            resident = sub_mode == "snp"
+            rec = pmc_record(sub_mode)
+            first_s = pr["first_ms"] / pr["first_launches"] * 1e-3
             first_achieved = first_bytes / first_s / 1e9
-            passes_per_launch = pr["pass_launches"] / max(1, pr["first_launches"]) if resident else 1.0
+            passes_per_launch = pr["pass_launches"] / pr["first_launches"] if resident else 1.0
             launches = pr["first_launches"] if resident else pr["pass_launches"]
             avg_s = pr["pass_ms"] / launches * 1e-3
             alg_bytes = passes_per_launch * pass_bytes
             achieved = alg_bytes / avg_s / 1e9
-            traffic = first_traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pass_kernel_pmc.json")
-            if os.path.exists(pmc):
-                try:
-                    for rec in json.load(open(pmc)).get("records", []):
-                        if (rec.get("n") == n and rec.get("k") == k and rec.get("n_gpus") == world
-                                and bool(rec.get("resident")) == resident):
-                            traffic = rec.get("hbm_bytes_per_launch")
-                            first_traffic = rec.get("first_pass_hbm_bytes_per_launch")
-                except Exception:  # noqa: BLE001
-                    pass
-            try:
-                read_us, rmw_us = eng.probe_stream(50)
-            except Exception as exc:  # noqa: BLE001 -- an extra, never fatal
-                read_us = rmw_us = None
-                print(f"[bench] stream probe skipped: {exc}", file=sys.stderr, flush=True)
             if resident:
                 kernel = (f"ts_resident<K> (all {passes_per_launch:.3g} plain passes of a SNP in one launch: weights read once, "
                           "kept in registers; partial rows exchanged inside the launch)")
@@ -372,10 +395,10 @@ def main():
                         "bytes: 64 MB at N=1M, K=8) every launch and they stay in the 256 MiB Infinity Cache; FETCH_SIZE counts "
                         "those hits.  probe_read_us is a bare streaming read of the same array with the same geometry on this "
                         "box (tsamd_probe_stream): the second denominator.")
-            roofline = {
+            per_snp = {
                 "bound": "hbm", "kernel": kernel,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("hbm_bytes_per_launch"),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_us": round(avg_s * 1e6, 3), "launches_timed": launches,
                 "passes_per_launch": round(passes_per_launch, 3),
@@ -386,13 +409,54 @@ def main():
                 "first_pass": {
                     "kernel": "ts_pass<K,true> (first pass of a SNP + the previous SNP's gamma step, 1 launch per update)",
                     "bound": "hbm", "achieved": round(first_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(first_achieved / HBM_PEAK_GBS, 4), "traffic": first_traffic,
+                    "frac": round(first_achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("first_pass_hbm_bytes_per_launch"),
                     "algorithmic_bytes_per_launch": first_bytes, "avg_launch_us": round(first_s * 1e6, 3),
                     "launches_timed": pr["first_launches"],
                     "probe_rmw_us": None if rmw_us is None else round(rmw_us, 3),
                     "frac_of_probe": None if rmw_us is None else round(rmw_us * 1e-6 / first_s, 4),
                 },
             }
+        if mode == "schedule":
+            # the dominant (only) kernel of the timed region: ONE launch runs the whole schedule.  Algorithmic bytes per
+            # launch = what the reference's dataflow moves for the updates of that launch: per update one first pass
+            # (32NK + 8N + N/2: weights and gamma read and written, c_n, two columns) + (passes - 1) plain passes (8NK + N/4).
+            nsteps = min(args.steps, 2000)
+            prs, ran = profiled(nsteps)
+            if prs["pass_launches"]:
+                rec = pmc_record("schedule")
+                launch_s = prs["pass_ms"] / prs["pass_launches"] * 1e-3
+                upd = nsteps / prs["pass_launches"]
+                alg_bytes = (nsteps * first_bytes + max(0, ran - nsteps) * pass_bytes) / prs["pass_launches"]
+                achieved = alg_bytes / launch_s / 1e9
+                moved = 16.0 * sc * k + 8.0 * sc + sc / 4.0   # what ts_schedule itself must move per update: gamma R+W, c_n R+W, a column
+                traffic = rec.get("hbm_bytes_per_update")
+                roofline = {
+                    "bound": "hbm",
+                    "kernel": (f"ts_schedule<K> (one launch = {upd:.0f} SNP updates: the gamma step and all {ran / nsteps:.3g} passes of every "
+                               "SNP; weights in registers from the first SNP to the last; partial rows exchanged inside the launch)"),
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None if traffic is None else traffic * upd,
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(launch_s * 1e6, 1),
+                    "launches_timed": prs["pass_launches"], "updates_per_launch": upd,
+                    "per_update_us": round(launch_s * 1e6 / upd, 3), "passes_per_update": round(ran / nsteps, 3),
+                    "algorithmic_bytes_per_update": alg_bytes / upd,
+                    "moved_bytes_per_update": moved,
+                    "moved_floor_us_per_update": round(moved / (HBM_PEAK_GBS * 1e9) * 1e6, 3),
+                    "ceiling_note": ("algorithmic bytes = the reference's dataflow (every pass re-reads the N x K weights, the gamma step "
+                                     "reads and writes weights and gamma).  ts_schedule keeps the weights in registers, so per update it "
+                                     "moves only moved_bytes_per_update (gamma read + write, c_n, one 2-bit column; `traffic` is the "
+                                     "counter-measured figure) and frac -- algorithmic bandwidth over the 8 TB/s HBM peak -- can exceed 1.  "
+                                     "What bounds the kernel instead (in-kernel timers of the diagnostic build, profiles/r02_experiments.md): "
+                                     "the gamma step's fp64 arithmetic (digamma + exp per individual and population, one wave per SIMD) and "
+                                     "the in-launch exchange of the partial rows (two dependent memory round trips per pass).  "
+                                     "launch_per_snp holds the kernels of the launch-per-SNP sequence on the same data (the default "
+                                     "mode for K > 8, sharded runs and larger shards), measured right after."),
+                    "launch_per_snp": per_snp,
+                    "first_pass": None if per_snp is None else per_snp["first_pass"],
+                    "probe_read_us": None if read_us is None else round(read_us, 3),
+                }
+        else:
+            roofline = per_snp
 
     # third denominator: what a plain device-to-device copy reaches on this box,
     # with the benchmark's data still resident (read + write bytes over the copy time)

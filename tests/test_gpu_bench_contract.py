@@ -32,7 +32,14 @@ def test_bench_json_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
     assert "N=30000 K=8" in d["metric"]                                       # names the workload that ran
-    assert rf["probe_read_us"] > 0 and "tsamd_probe_stream" in rf["ceiling_note"] and rf["passes_per_launch"] == 1.0
+    # one GPU, K = 8: the whole schedule is one launch of ts_schedule; the kernels of the launch-per-SNP
+    # sequence are timed beside it
+    assert "ts_schedule" in rf["kernel"] and rf["updates_per_launch"] == 60 and rf["launches_timed"] == 1
+    assert rf["algorithmic_bytes_per_update"] > rf["moved_bytes_per_update"] == 16.0 * 30000 * 8 + 8.0 * 30000 + 30000 / 4.0
+    assert abs(rf["per_update_us"] * rf["updates_per_launch"] - rf["avg_launch_us"]) < 0.1 * rf["avg_launch_us"]
+    ps = rf["launch_per_snp"]
+    assert "ts_resident" in ps["kernel"] and ps["probe_read_us"] > 0 and "tsamd_probe_stream" in ps["ceiling_note"]
+    assert ps["passes_per_launch"] > 1.0 and abs(ps["frac"] - ps["achieved"] / ps["peak"]) < 1e-3
     fp = rf["first_pass"]
     assert fp["bound"] == "hbm" and abs(fp["frac"] - fp["achieved"] / fp["peak"]) < 1e-3 and fp["probe_rmw_us"] > 0
     assert fp["algorithmic_bytes_per_launch"] == 32.0 * 30000 * 8 + 8.0 * 30000 + 30000 / 2.0

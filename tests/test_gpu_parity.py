@@ -193,6 +193,7 @@ def test_split_epilogue_path_bitwise(ts, n, l, k):
     for flags in (0, ts.FLAG_SPLIT_EPILOGUE):
         eng, _, _ = make_pair(ts, n, l, k, 55, flags=flags)
         with eng:
+            eng.set_launch_mode(ts.LAUNCH_PER_PASS)  # (the resident kernels add the partial rows in another order)
             eng.run_schedule(locs)
             eng.synchronize()
             res.append((eng.get_lambda(), eng.get_gamma()))
@@ -206,6 +207,7 @@ def test_rccl_single_rank_allreduce(ts):
     locs = np.random.default_rng(6).integers(0, l, size=12).astype(np.uint32)
     ref, _, _ = make_pair(ts, n, l, k, 88)
     with ref:
+        ref.set_launch_mode(ts.LAUNCH_PER_PASS)  # (same summation order as the sharded sequence)
         ref.run_schedule(locs)
         ref.synchronize()
         want = (ref.get_lambda(), ref.get_gamma())
