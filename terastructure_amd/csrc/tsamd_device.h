@@ -175,6 +175,16 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return fma(r, e, r);
 }
 
+// 1/sqrt(x) for positive normal x: hardware estimate + two Newton steps (about 1 ulp) instead of an IEEE
+// square root followed by an IEEE division (ts_schedule, whose gamma step is bound by its fp64 arithmetic).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-(x * y), y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-(x * y), y, 1.0);
+  return fma(0.5 * y, e, y);
+}
+
 // exp(psi(x)) split as z * exp(a): z = x + 10, a = u(z) - r(x) with
 // u = -1/(2z) - sum B2n/(2n z^2n) (the asymptotic series of psi(z) - log z, |u| <= 0.051) and
 // r = sum_{i<10} 1/(x+i).  Pairing the terms i and 9-i gives r = (2x+9) * Q'(q)/Q(q) with
