@@ -1231,6 +1231,23 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
 // (I + 3) 8NK to 16NK (gamma read + write); w is written back once, at the end of the launch.
 // Same semantics as the launch-per-pass state machine: starts from the State the previous call
 // left (its last SNP complete, its gamma step possibly pending) and leaves such a State.
+// ts_schedule: how many of a thread's items keep their gamma in LDS (per item: K rows x 16 bytes + c_n for 256 threads;
+// 4 KB of the 160 KB stay free for the small arrays), and which streamed item follows item t (items = none)
+constexpr int sched_lds_items(int k, int items) {
+#ifdef TSAMD_SCHED_LDS_ITEMS  // (experiments, tools/variant.sh)
+  return TSAMD_SCHED_LDS_ITEMS < items ? TSAMD_SCHED_LDS_ITEMS : items;
+#else
+  const int per_item = (k * 16 + 8) * 256, n = (160 * 1024 - 4096) / per_item;
+  return n < items ? n : items;
+#endif
+}
+constexpr int sched_next_streamed(int t, int k, int items) {
+  const int lds = sched_lds_items(k, items);
+  for (int u = t + 1; u < items; ++u)
+    if (((u + 1) * lds) / items == (u * lds) / items) return u;
+  return items;
+}
+
 template <int KT>
 __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
                                                       const uint32_t *sched, uint32_t n_sched, ResXchg *xb, const DevParams p) {
@@ -1241,6 +1258,14 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   __shared__ double s_eb[J], s_lam[J], s_diff[J], s_tot[J], s_sb[J], s_plam[J], s_peb[J];
   __shared__ double s_red[kWaves][J];
   __shared__ int s_alive;
+  // gamma (and c_n) of kLds of a thread's eight items stay in LDS for the whole launch -- at K = 8 that is 4 x 32 KB of the
+  // 160 KB, every second item; at K <= 4 all of them -- so the gamma step streams only the others from memory, one item ahead
+  // and spread evenly over the step.  Memory sees them again when the launch ends.
+  constexpr int kLds = sched_lds_items(KT, kItems);
+  __shared__ WT s_gam[kLds > 0 ? kLds : 1][KT][BLOCK];
+  __shared__ uint2 s_cn[kLds > 0 ? kLds : 1][BLOCK];
+  auto is_lds = [](int t) { return ((t + 1) * kLds) / kItems != (t * kLds) / kItems; };
+  auto lds_slot = [](int t) { return (t * kLds) / kItems; };
   const uint32_t par = par_arg & 1u;
   Ctl *ctl = ctl_a;
   const State *S = &ctl->st[par ^ 1u];
@@ -1273,6 +1298,14 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     for (int k = 0; k < KT; ++k) buf[t][k] = reinterpret_cast<const WT *>(w_a + (size_t)k * np)[item_or_last((uint32_t)t)];
     if (t & 1) __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll
+  for (int t = 0; t < kItems; ++t)
+    if (is_lds(t)) {
+      const uint32_t i = item_or_last((uint32_t)t);
+#pragma unroll
+      for (int k = 0; k < KT; ++k) s_gam[lds_slot(t)][k][tid] = reinterpret_cast<const WT *>(p.gam + (size_t)k * np)[i];
+      s_cn[lds_slot(t)][tid] = reinterpret_cast<const uint2 *>(p.cnt)[i];
+    }
   auto get_item = [&](int t, WT (&wv)[KT]) {
 #pragma unroll
     for (int k = 0; k < KT; ++k) wv[k] = buf[t][k];
@@ -1459,26 +1492,34 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     // thread's range is processed with "missing" codes and only its stores are guarded; an unobserved
     // genotype computes and discards (selects, no branch around assignments to the resident weights).
     if (do_gamma) {
-      WT gv[KT], gv_n[KT];
-      uint2 cv, cv_n;
+      WT gs[KT];  // the streamed item in flight (requested one streamed item ahead)
+      uint2 cs;
       auto load_gamma = [&](uint32_t i, WT (&gq)[KT], uint2 &cq) {
 #pragma unroll
         for (int k = 0; k < KT; ++k) gq[k] = reinterpret_cast<const WT *>(p.gam + (size_t)k * np)[i];
         cq = reinterpret_cast<const uint2 *>(p.cnt)[i];
       };
-      load_gamma(item_or_last(0), gv, cv);
+      constexpr int kFirstStreamed = sched_next_streamed(-1, KT, kItems);
+      if (kFirstStreamed < kItems) load_gamma(item_or_last((uint32_t)kFirstStreamed), gs, cs);
 #pragma unroll
       for (int t = 0; t < kItems; ++t) {
         fresh();
         const uint32_t i = item_or_last((uint32_t)t);
         const bool mine = (uint32_t)t < cnt;
-#ifdef TSAMD_EXP_NOGAMMAMEM  // timing experiment only (wrong results): no gamma traffic after the first item
+        WT gv[KT];
+        uint2 cv;
+        if (is_lds(t)) {
 #pragma unroll
-        for (int k = 0; k < KT; ++k) gv_n[k] = gv[k];
-        cv_n = cv;
-#else
-        load_gamma(item_or_last((uint32_t)t + 1u), gv_n, cv_n);  // (clamped: the last one is a harmless re-read)
-#endif
+          for (int k = 0; k < KT; ++k) gv[k] = s_gam[lds_slot(t)][k][tid];
+          cv = s_cn[lds_slot(t)][tid];
+        } else {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) gv[k] = gs[k];
+          cv = cs;
+          constexpr int kNone = kItems;
+          const int nxt = sched_next_streamed(t, KT, kItems);
+          if (nxt < kNone) load_gamma(item_or_last((uint32_t)nxt), gs, cs);
+        }
         __builtin_amdgcn_sched_barrier(0);
         WT wcur[KT];
         get_item(t, wcur);
@@ -1527,19 +1568,16 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
             wcur[k].y = wx[k];
           }
         }
-#ifdef TSAMD_EXP_NOGAMMAMEM
-        if (mine && gv[0].x == 123.456) {
-#else
-        if (mine) {
-#endif
+        if (is_lds(t)) {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) s_gam[lds_slot(t)][k][tid] = gv[k];
+          s_cn[lds_slot(t)][tid] = cv;
+        } else if (mine) {
 #pragma unroll
           for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = gv[k];
           reinterpret_cast<uint2 *>(p.cnt)[i] = cv;
         }
         put_item(t, wcur);
-#pragma unroll
-        for (int k = 0; k < KT; ++k) gv[k] = gv_n[k];
-        cv = cv_n;
         __builtin_amdgcn_sched_barrier(0);
       }
       w_dirty = true;
@@ -1617,6 +1655,11 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         get_item(t, wcur);
 #pragma unroll
         for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(w_a + (size_t)k * np)[i] = wcur[k];
+        if (is_lds(t)) {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = s_gam[lds_slot(t)][k][tid];
+          reinterpret_cast<uint2 *>(p.cnt)[i] = s_cn[lds_slot(t)][tid];
+        }
       }
     }
   }
