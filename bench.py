@@ -428,7 +428,10 @@ def main():
                 upd = nsteps / prs["pass_launches"]
                 alg_bytes = (nsteps * first_bytes + max(0, ran - nsteps) * pass_bytes) / prs["pass_launches"]
                 achieved = alg_bytes / launch_s / 1e9
-                moved = 16.0 * sc * k + 8.0 * sc + sc / 4.0   # what ts_schedule itself must move per update: gamma R+W, c_n R+W, a column
+                # what ts_schedule itself must move per update: gamma and c_n, read and written, of the items whose gamma
+                # is not kept in LDS (csrc/tsamd_kernels.h: sched_lds_items -- half of them at K = 8, none at K <= 4), a column
+                n_lds = min(8, (160 * 1024 - 4096) // ((k * 16 + 8) * 256))
+                moved = (16.0 * sc * k + 8.0 * sc) * (8 - n_lds) / 8.0 + sc / 4.0
                 traffic = rec.get("hbm_bytes_per_update")
                 roofline = {
                     "bound": "hbm",

@@ -1043,7 +1043,7 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   c->sched_busy.push_back(stage);
   uint32_t *ent = stage.first;
   for (uint32_t i = 0; i < n; ++i) ent[i] = locs[i] | (hol_mode ? 0x80000000u : 0u);
-  if (n > c->sched_cap) {
+  if (!c->persistent && n > c->sched_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     hipFree(c->d_sched);
     c->d_sched = nullptr;
@@ -1059,8 +1059,9 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   const bool use_graph = graphs_allowed(c);
   if (use_graph)
     if (int rc = ensure_graphs(c)) return rc;
-  HIP_TRY(c, hipMemcpyAsync(c->d_sched, ent, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   if (c->persistent) {
+    // (the kernel reads the entries straight from the pinned staging buffer, one SNP ahead of their use: no copy
+    // to wait for at the start of a short schedule; the buffer is recycled at tsamd_synchronize)
     // one launch runs the whole schedule (in pieces of kScheduleChunk SNPs): it starts from the State the
     // previous call left and leaves one like ts_flush does -- no ts_begin, no ts_flush
     for (uint32_t off = 0; off < n; off += kScheduleChunk) {
@@ -1072,7 +1073,7 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
         if (int rc = prof_event(c, c->ev_pass, 2 * c->n_ev_pass, &e)) return rc;
         HIP_TRY(c, hipEventRecord(e, c->stream));
       }
-      kScheduleLaunchers[c->cfg.k](c->grid, c->stream, c->p, next_parity(c), c->d_sched + off, len);
+      kScheduleLaunchers[c->cfg.k](c->grid, c->stream, c->p, next_parity(c), ent + off, len);
       if (prof) {
         if (int rc = prof_event(c, c->ev_pass, 2 * c->n_ev_pass + 1, &e)) return rc;
         HIP_TRY(c, hipEventRecord(e, c->stream));
@@ -1082,6 +1083,7 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
     HIP_TRY(c, hipGetLastError());
     return TSAMD_OK;
   }
+  HIP_TRY(c, hipMemcpyAsync(c->d_sched, ent, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   enqueue_begin(c, n, false);
   if (use_graph) {
     const uint32_t per_snp = kernels_per_snp(c);

@@ -1680,7 +1680,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       W->epoch = epoch_now;
       ctl->xseq = xseq0 + xcount;
 #ifdef TSAMD_SCHED_TIME
-      if (n_sched > 100u)
+      if (n_sched >= 16u)
         printf("ts_schedule n=%u exchanges=%u | per SNP (us): head %.2f gamma %.2f first pass %.2f later passes %.2f tail %.2f | "
                "in exchanges %.2f | whole launch %.1f us\n", n_sched, xcount, tk_head * 0.01 / n_sched, tk_gamma * 0.01 / n_sched,
                tk_first * 0.01 / n_sched, tk_rest * 0.01 / n_sched, tk_tail * 0.01 / n_sched, tk_xchg * 0.01 / n_sched,
