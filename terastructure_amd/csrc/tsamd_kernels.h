@@ -1248,7 +1248,7 @@ constexpr int sched_next_streamed(int t, int k, int items) {
   return items;
 }
 
-template <int KT>
+template <int KT, bool PARTIAL>
 __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
                                                       const uint32_t *sched, uint32_t n_sched, ResXchg *xb, const DevParams p) {
   constexpr int BLOCK = 256, kWaves = BLOCK / 64, kItems = kResidentItems;
@@ -1284,6 +1284,10 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   // hundred values, spilled -- so the three values they derive from are made opaque per use.
   auto fresh = [&]() { asm volatile("" : "+v"(tid), "+v"(i0), "+v"(cnt)); };
   auto item_or_last = [&](uint32_t t) { return cnt ? i0 + min(t, cnt - 1u) * BLOCK : min(i0, nitems - 1u); };
+  // items any thread of this workgroup owns (uniform).  PARTIAL (the host picks it when a workgroup's chunk leaves
+  // whole items unused: shards well below 1M individuals): the item bodies nobody needs are skipped; the branches
+  // cost the full-size kernel 5 %, so it runs without them -- an unused item is then processed as "missing".
+  const uint32_t cnt_wg = !PARTIAL ? (uint32_t)kItems : begin < end ? min((end - begin + BLOCK - 1u) / BLOCK, (uint32_t)kItems) : 0u;
   const uint32_t g = blockIdx.x % (uint32_t)kResGroups, m = blockIdx.x / (uint32_t)kResGroups;
 
   if (n_sched == 0u) {
@@ -1503,6 +1507,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       if (kFirstStreamed < kItems) load_gamma(item_or_last((uint32_t)kFirstStreamed), gs, cs);
 #pragma unroll
       for (int t = 0; t < kItems; ++t) {
+        if (PARTIAL && (uint32_t)t >= cnt_wg) continue;
         fresh();
         const uint32_t i = item_or_last((uint32_t)t);
         const bool mine = (uint32_t)t < cnt;
@@ -1587,6 +1592,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     begin_pass();
 #pragma unroll
     for (int t = 0; t < kItems; ++t) {
+      if (PARTIAL && (uint32_t)t >= cnt_wg) continue;
       fresh();
       WT wcur[KT];
       get_item(t, wcur);
@@ -1604,6 +1610,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       begin_pass();
 #pragma unroll
       for (int t = 0; t < kItems; ++t) {
+        if (PARTIAL && (uint32_t)t >= cnt_wg) continue;
         fresh();
         WT wcur[KT];
         get_item(t, wcur);

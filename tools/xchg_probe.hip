@@ -195,11 +195,17 @@ __global__ __launch_bounds__(512) void probe(Xb *xb, int passes, unsigned tag0, 
   }
 }
 
-int main() {
+int main(int argc, char **argv) {
   Xb *xb;
   double *out;
   const int grid = kGroups * kPerGroup;
-  CK(hipMalloc(&xb, sizeof(Xb)));
+  // argv[1]: 0 = hipMalloc (default), 1 = fine-grained, 2 = uncached device memory for the exchange buffer
+  const int kind = argc > 1 ? atoi(argv[1]) : 0;
+  const int max_var = argc > 2 ? atoi(argv[2]) : 9;
+  if (kind == 0) CK(hipMalloc(&xb, sizeof(Xb)));
+  if (kind == 1) CK(hipExtMallocWithFlags((void **)&xb, sizeof(Xb), hipDeviceMallocFinegrained));
+  if (kind == 2) CK(hipExtMallocWithFlags((void **)&xb, sizeof(Xb), hipDeviceMallocUncached));
+  printf("exchange buffer: %s\n", kind == 0 ? "hipMalloc" : kind == 1 ? "fine-grained" : "uncached");
   CK(hipMemset(xb, 0, sizeof(Xb)));
   CK(hipMalloc(&out, 2 * grid * sizeof(double)));
   hipEvent_t e0, e1;
@@ -214,7 +220,7 @@ int main() {
     if (var >= 4) hipLaunchKernelGGL(probe<7>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, 1u << (var - 3));
     tag0 += passes;
   };
-  for (int var = 0; var < 9; ++var) {
+  for (int var = 0; var < max_var; ++var) {
     printf("variant %d (%s)\n", var, var == 0 ? "agent scope on both levels" : var == 1 ? "level 1 through the XCD's L2 (sc0)" :
            var == 2 ? "level 1 through the L2, leaders all-to-all at agent scope, total handed back through the L2" :
            var == 3 ? "agent scope, four waves poll out of phase (150 ns apart)" :
