@@ -114,6 +114,8 @@ struct tsamd_ctx {
   bool resident = false;    // plain passes of a SNP run as ONE launch (ts_resident) instead of max_inner - 1
   bool persistent = false;  // ... and a whole schedule runs as ONE launch (ts_schedule: the weights never leave the registers)
   bool can_resident = false, can_persistent = false;  // what the context qualifies for (tsamd_set_launch_mode)
+  uint32_t sched_grid = 0, sched_chunk = 0;  // launch geometry of ts_schedule (= the plain pass' on one GPU; its own when sharded)
+  uint32_t device_share = 1;  // contexts whose resident kernels share this device (tests: several ranks on one GPU)
   ResXchg *res = nullptr;   // their in-launch exchange buffer
   unsigned long long *h_error = nullptr;  // pinned: tag of a bounded in-kernel wait that gave up (0: none)
   // profiling
@@ -166,7 +168,7 @@ int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
   int first_blocks_per_cu_k##k(int);                                                               \
   int resident_blocks_per_cu_k##k();
 #define TSAMD_SCHED_DECL(k)                                                                       \
-  void launch_schedule_k##k(uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t); \
+  void launch_schedule_k##k(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t); \
   int schedule_blocks_per_cu_k##k();
 #define TSAMD_SCHED_K(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #define TSAMD_ALL_K(X)                                                                             \
@@ -185,7 +187,7 @@ int (*const kFirstBlocksPerCu[TSAMD_SPECIALIZED_K + 1])(int) = {nullptr, TSAMD_A
 #define TSAMD_RES_ENTRY(k) tsamd::resident_blocks_per_cu_k##k,
 int (*const kResidentBlocksPerCu[TSAMD_SPECIALIZED_K + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_RES_ENTRY)};
 static_assert(kResidentMaxK == 8, "TSAMD_SCHED_K lists K = 1 .. kResidentMaxK");
-typedef void (*ScheduleFn)(uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t);
+typedef void (*ScheduleFn)(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t);
 #define TSAMD_SCHED_ENTRY(k) tsamd::launch_schedule_k##k,
 const ScheduleFn kScheduleLaunchers[kResidentMaxK + 1] = {nullptr, TSAMD_SCHED_K(TSAMD_SCHED_ENTRY)};
 #define TSAMD_SCHED_OCC_ENTRY(k) tsamd::schedule_blocks_per_cu_k##k,
@@ -414,6 +416,44 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
   geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", first_target), p.chunk_first, c->grid_first);
 }
 
+// ts_schedule on a shard: one launch per rank and schedule, weights resident, level 2 of the in-launch exchange across
+// the ranks (Xchg::res_sums).  Every rank must reach the same verdict, so it depends only on the configuration: up to 8
+// ranks, K <= 8, the reference's default learning-rate exponent, every rank's shard fits the register file of at most
+// min(256, CUs / device_share) workgroups and fills at least 8 of them (all 8 groups of every rank then post a sum).
+void choose_sharded_schedule(tsamd_ctx *c) {
+  const tsamd_config &cfg = c->cfg;
+  if (c->wide || cfg.world > 8u || (int)cfg.k > kResidentMaxK || cfg.nodekappa != 0.5 || cfg.max_inner < 2u || cfg.max_inner > 200u ||
+      env_u32("TSAMD_RESIDENT", 1) == 0u || env_u32("TSAMD_PERSISTENT", 1) == 0u || kScheduleBlocksPerCu[cfg.k]() < 1)
+    return;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c->dev) != hipSuccess || prop.multiProcessorCount <= 0) return;
+  c->device_share = std::max<uint32_t>(c->device_share, env_u32("TSAMD_DEVICE_SHARE", 1));
+  const uint32_t cap = std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)prop.multiProcessorCount / c->device_share);
+  if (cap < (uint32_t)kResGroups) return;
+  uint32_t my_grid = 0, my_chunk = 0;
+  for (uint32_t r = 0; r < cfg.world; ++r) {
+    uint32_t b = 0, cnt = 0;
+    tsamd_shard_range(cfg.n, r, cfg.world, &b, &cnt);
+    const uint32_t npairs = (cnt + 511u) / 512u * 256u;
+    uint32_t chunk = (npairs + cap - 1u) / cap;
+    chunk = (chunk + (uint32_t)kResidentBlock - 1u) / (uint32_t)kResidentBlock * (uint32_t)kResidentBlock;
+    const uint32_t grid = (npairs + chunk - 1u) / chunk;
+    if (chunk > (uint32_t)(kResidentItems * kResidentBlock) || grid < (uint32_t)kResGroups) return;
+    if (r == cfg.rank) {
+      my_grid = grid;
+      my_chunk = chunk;
+    }
+  }
+  if (!c->res) {
+    if (hipMalloc((void **)&c->res, sizeof(ResXchg)) != hipSuccess) return;
+    if (hipMemsetAsync(c->res, 0, sizeof(ResXchg), c->stream) != hipSuccess) return;
+    c->p.res = c->res;
+  }
+  c->sched_grid = my_grid;
+  c->sched_chunk = my_chunk;
+  c->persistent = c->can_persistent = true;
+}
+
 // Switch the kernel sequence to the exchange buffer (rows + epoch flags pushed by every
 // workgroup to every rank); p.peers[] must be filled in.
 void activate_xchg(tsamd_ctx *c) {
@@ -427,6 +467,7 @@ void activate_xchg(tsamd_ctx *c) {
   c->resident = c->persistent = c->can_resident = c->can_persistent = false;
   c->p2p = true;
   configure_launch(c, std::max<uint32_t>(16u, std::min<uint32_t>(kXchgBlocks, 512u / c->cfg.world)));
+  choose_sharded_schedule(c);
 }
 
 int alloc_xchg(tsamd_ctx *c) {
@@ -635,6 +676,8 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
                     kScheduleBlocksPerCu[cfg->k]() >= 1;
     c->can_resident = c->resident;
     c->can_persistent = c->persistent;
+    c->sched_grid = c->grid;
+    c->sched_chunk = p.chunk;
   }
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
@@ -1073,7 +1116,7 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
         if (int rc = prof_event(c, c->ev_pass, 2 * c->n_ev_pass, &e)) return rc;
         HIP_TRY(c, hipEventRecord(e, c->stream));
       }
-      kScheduleLaunchers[c->cfg.k](c->grid, c->stream, c->p, next_parity(c), ent + off, len);
+      kScheduleLaunchers[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), ent + off, len);
       if (prof) {
         if (int rc = prof_event(c, c->ev_pass, 2 * c->n_ev_pass + 1, &e)) return rc;
         HIP_TRY(c, hipEventRecord(e, c->stream));
@@ -1118,7 +1161,7 @@ int tsamd_prepare(tsamd_ctx *c) {
   HIP_TRY(c, hipSetDevice(c->dev));
   if (c->cfg.world > 1 && !c->comm && !c->p2p) return TSAMD_OK;  // exchange not chosen yet: nothing to capture
   if (c->persistent) {  // an empty schedule: the kernel's code object is loaded, the state only carried forward
-    kScheduleLaunchers[c->cfg.k](c->grid, c->stream, c->p, next_parity(c), c->d_sched, 0u);
+    kScheduleLaunchers[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), c->d_sched, 0u);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return TSAMD_OK;
@@ -1148,6 +1191,10 @@ int tsamd_synchronize(tsamd_ctx *c) {
   c->sched_busy.clear();
   if (c->h_error && *(volatile unsigned long long *)c->h_error != 0ull) {  // (written by the kernel that gave up)
     const unsigned long long err = *(volatile unsigned long long *)c->h_error;
+    if (c->p2p && c->persistent)
+      return fail(c, TSAMD_ECOMM, "ts_schedule: the in-launch exchange across %u ranks timed out (tag %llu): a peer did not arrive, or "
+                  "not all workgroups of all ranks are resident (ranks that share one device: TSAMD_DEVICE_SHARE=<ranks>)",
+                  c->cfg.world, err);
     if (c->p2p) return fail(c, TSAMD_ECOMM, "peer-to-peer exchange timed out waiting for a peer (epoch %llu)", err);
     return fail(c, TSAMD_EHIP, "%s: the in-launch exchange timed out (tag %llu): are all %u workgroups resident?  "
                 "TSAMD_PERSISTENT=0 selects one launch per SNP for the plain passes, TSAMD_RESIDENT=0 one launch per pass",
@@ -1416,9 +1463,16 @@ int tsamd_p2p_connect_local(tsamd_ctx *const *ctxs, uint32_t count) {
         return fail(c, TSAMD_ECOMM, "hipDeviceEnablePeerAccess(%d -> %d): %s", c->dev, o->dev, hipGetErrorString(e));
     }
   }
+  uint32_t share = 1;  // contexts on the busiest device: their resident kernels must fit it together
+  for (tsamd_ctx *c : by_rank) {
+    uint32_t same = 0;
+    for (tsamd_ctx *o : by_rank) same += o->dev == c->dev ? 1u : 0u;
+    share = std::max(share, same);
+  }
   for (tsamd_ctx *c : by_rank) {
     HIP_TRY(c, hipSetDevice(c->dev));
     for (uint32_t q = 0; q < count; ++q) c->p.peers[q] = by_rank[q]->xchg;
+    c->device_share = share;
     activate_xchg(c);
     if (c->wide && c->p.chunk_first > (uint32_t)kWideBlock * kWideItems)
       return fail(c, TSAMD_EUNSUPPORTED, "wide-K fallback: shard too large for the peer-to-peer launch geometry");
@@ -1554,13 +1608,13 @@ int tsamd_launch_info(tsamd_ctx *c, uint32_t *kernels_per_snp_out, uint32_t *pla
 int tsamd_set_launch_mode(tsamd_ctx *c, int mode) {
   CHECK_CTX(c);
   if (mode < TSAMD_LAUNCH_PER_PASS || mode > TSAMD_LAUNCH_PER_SCHEDULE) return fail(c, TSAMD_EINVAL, "launch mode %d", mode);
-  if ((mode >= TSAMD_LAUNCH_PER_SNP && !c->can_resident) || (mode == TSAMD_LAUNCH_PER_SCHEDULE && !c->can_persistent))
+  if ((mode == TSAMD_LAUNCH_PER_SNP && !c->can_resident) || (mode == TSAMD_LAUNCH_PER_SCHEDULE && !c->can_persistent))
     return fail(c, TSAMD_EUNSUPPORTED, "launch mode %d needs one GPU, k <= %d, a shard that fits the register file%s", mode,
                 kResidentMaxK, mode == TSAMD_LAUNCH_PER_SCHEDULE ? " and nodekappa == 0.5" : "");
   if (int rc = tsamd_synchronize(c)) return rc;
-  const bool resident = mode >= TSAMD_LAUNCH_PER_SNP, persistent = mode == TSAMD_LAUNCH_PER_SCHEDULE;
+  const bool resident = mode >= TSAMD_LAUNCH_PER_SNP && c->can_resident, persistent = mode == TSAMD_LAUNCH_PER_SCHEDULE;
   if (resident != c->resident) destroy_graph(c);  // (captured for the other kernel sequence)
-  c->resident = resident;
+  c->resident = resident;  // (a sharded context has no launch-per-SNP mode: ts_schedule or one launch per pass)
   c->persistent = persistent;
   return TSAMD_OK;
 }

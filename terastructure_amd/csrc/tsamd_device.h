@@ -85,6 +85,10 @@ struct Xchg {
   // overwrites a slot: two slots are then always enough.
   unsigned long long prog[kMaxRanks];
   unsigned long long error;  // a bounded wait gave up
+  // ts_schedule on several GPUs: level 2 of its in-launch exchange (ResXchg below).  The leader of group g of rank r
+  // stores its group sum as granules into res_sums[parity][r * 8 + g] of EVERY rank's buffer (8-byte system-scope
+  // stores over xGMI); every workgroup then polls its own rank's copy -- local memory -- for world * 8 rows.
+  unsigned long long res_sums[2][kMaxRanks * 8][32];
 };
 
 // In-launch exchange of the resident plain-pass kernel (ts_resident; single GPU): per pass every
@@ -96,7 +100,7 @@ struct Xchg {
 //            and publishes sums[pass & 1][g];
 //   level 2: every workgroup re-reads the 8 leader rows and adds them in group order.
 // tag = 256 * launch epoch + pass: never repeats, so nothing is re-initialised between launches.
-constexpr int kResGroups = 8;
+constexpr int kResGroups = 8;     // (Xchg::res_sums is laid out for these two)
 constexpr int kResMembers = 32;  // workgroups per group (grid <= 256)
 constexpr int kResGran = 32;     // granules per row: 2 per value, 2K <= 16 values
 struct ResXchg {

@@ -993,6 +993,42 @@ __device__ __forceinline__ double res_sum(const unsigned (&v)[N], uint32_t lane)
   return s + __shfl_xor(s, 32);
 }
 
+// Level 2 across ranks (ts_schedule, sharded): N row pairs of this rank's Xchg::res_sums slot, written by the group
+// leaders of all ranks with system-scope stores; rows >= nrows (world * 8) do not exist.  Returns the fixed-order
+// total in lanes 2 j like res_sum; false when the bounded wait gave up.
+template <int N>
+__device__ __forceinline__ bool res_sweep_ranks(const unsigned long long *base, uint32_t tag, uint32_t nvalid_gran, uint32_t nrows,
+                                                double &total, unsigned long long *abort_word, unsigned long long *host_flag,
+                                                uint32_t lane) {
+  const uint32_t c = lane & 31u;
+  const unsigned long long t0 = wall_clock64();
+  unsigned v[N];
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t row = 2u * (uint32_t)i + (lane >> 5);
+      const bool exists = c < nvalid_gran && row < nrows;
+      const unsigned long long x = __hip_atomic_load(base + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v[i] = exists ? (unsigned)x : 0u;
+      ok &= !exists || (unsigned)(x >> 32) == tag;
+    }
+    if (__all(ok)) break;
+    if (wall_clock64() - t0 > 300000000ull ||  // 3 s
+        __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
+      if (lane == 0) {
+        __hip_atomic_store(abort_word, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (host_flag) __hip_atomic_store(host_flag, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      total = 0.0;
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  total = res_sum<N>(v, lane);
+  return true;
+}
+
 template <int KT>
 __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partials_a, double *w_a, uint32_t npad_a, uint32_t chunk_a,
                                                       uint32_t par_arg, uint32_t nrows_hint, ResXchg *xb, const DevParams p) {
@@ -1248,7 +1284,7 @@ constexpr int sched_next_streamed(int t, int k, int items) {
   return items;
 }
 
-template <int KT, bool PARTIAL>
+template <int KT, bool PARTIAL, int WR>
 __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
                                                       const uint32_t *sched, uint32_t n_sched, ResXchg *xb, const DevParams p) {
   constexpr int BLOCK = 256, kWaves = BLOCK / 64, kItems = kResidentItems;
@@ -1437,16 +1473,30 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         const double s = res_sum<kResMembers / 2>(v, lane);
         if (lane < 2 * J && !(lane & 1u)) {
           const unsigned long long bits = __double_as_longlong(s);
-          __hip_atomic_store(&xb->sums[tag & 1u][g][lane], ((unsigned long long)tag << 32) | (uint32_t)bits, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&xb->sums[tag & 1u][g][lane + 1], ((unsigned long long)tag << 32) | (uint32_t)(bits >> 32),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long glo = ((unsigned long long)tag << 32) | (uint32_t)bits;
+          const unsigned long long ghi = ((unsigned long long)tag << 32) | (uint32_t)(bits >> 32);
+          if constexpr (WR == 0) {
+            __hip_atomic_store(&xb->sums[tag & 1u][g][lane], glo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&xb->sums[tag & 1u][g][lane + 1], ghi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {  // sharded: the group sum goes to every rank (this one included), straight over xGMI
+            for (uint32_t r = 0; r < p.xchg_world; ++r) {
+              unsigned long long *dst = &p.peers[r]->res_sums[tag & 1u][p.xchg_rank * (uint32_t)kResGroups + g][lane];
+              __hip_atomic_store(dst, glo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(dst + 1, ghi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+          }
         }
       }
-      unsigned v2[kResGroups / 2];
-      alive = res_sweep<kResGroups / 2>(&xb->sums[tag & 1u][0][0], tag, 2 * J, 0u, gridDim.x, false, v2, &xb->abort_word,
-                                        p.host_error, lane) && alive;
-      const double s = res_sum<kResGroups / 2>(v2, lane);
+      double s = 0.0;
+      if constexpr (WR == 0) {
+        unsigned v2[kResGroups / 2];
+        alive = res_sweep<kResGroups / 2>(&xb->sums[tag & 1u][0][0], tag, 2 * J, 0u, gridDim.x, false, v2, &xb->abort_word,
+                                          p.host_error, lane) && alive;
+        s = res_sum<kResGroups / 2>(v2, lane);
+      } else {  // (every rank runs at least 8 workgroups -- the host checks -- so all world * 8 rows exist)
+        alive = res_sweep_ranks<WR>(&p.xchg->res_sums[tag & 1u][0][0], tag, 2 * J, p.xchg_world * (uint32_t)kResGroups, s,
+                                    &xb->abort_word, p.host_error, lane) && alive;
+      }
       if (lane < 2 * J && !(lane & 1u)) s_tot[lane >> 1] = s;
       if (lane == 0) s_alive = alive ? 1 : 0;
     }

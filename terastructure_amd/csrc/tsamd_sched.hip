@@ -14,24 +14,45 @@ namespace tsamd {
 
 static_assert(TSAMD_K <= kResidentMaxK, "ts_schedule holds the shard's weights in registers: K <= 8");
 
-// n entries at `sched` (device memory), starting from and leaving the State of parity par
-void TSAMD_CAT(launch_schedule_k, TSAMD_K)(uint32_t grid, hipStream_t stream, const DevParams &p, uint32_t par, const uint32_t *sched,
-                                           uint32_t n) {
-  // a chunk that fills all eight items of its threads runs the kernel without the skip-unused-items branches
-  if (p.chunk > (uint32_t)((kResidentItems - 1) * kResidentBlock))
-    hipLaunchKernelGGL((ts_schedule<TSAMD_K, false>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.w, p.npad, p.chunk, par,
-                       sched, n, p.res, p);
-  else
-    hipLaunchKernelGGL((ts_schedule<TSAMD_K, true>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.w, p.npad, p.chunk, par,
-                       sched, n, p.res, p);
+// n entries at `sched` (pinned host or device memory), starting from and leaving the State of parity par.
+// A chunk that fills all eight items of its threads runs the kernel without the skip-unused-items branches; a sharded
+// context (p.xchg_world ranks connected peer to peer) runs the instantiation whose level 2 spans the ranks' group
+// leaders (8 row pairs per lane for up to 2 ranks, 16 for up to 4, 32 for up to 8).
+#define TSAMD_SCHED_LAUNCH(PARTIAL, WR)                                                                                            \
+  hipLaunchKernelGGL((ts_schedule<TSAMD_K, PARTIAL, WR>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.w, p.npad, chunk, par, \
+                     sched, n, p.res, p)
+void TSAMD_CAT(launch_schedule_k, TSAMD_K)(uint32_t grid, uint32_t chunk, hipStream_t stream, const DevParams &p, uint32_t par,
+                                           const uint32_t *sched, uint32_t n) {
+  const bool partial = chunk <= (uint32_t)((kResidentItems - 1) * kResidentBlock);
+  const uint32_t world = p.xchg_world;
+  if (world == 0u) {
+    if (partial) TSAMD_SCHED_LAUNCH(true, 0); else TSAMD_SCHED_LAUNCH(false, 0);
+  } else if (world <= 2u) {
+    if (partial) TSAMD_SCHED_LAUNCH(true, 8); else TSAMD_SCHED_LAUNCH(false, 8);
+  } else if (world <= 4u) {
+    if (partial) TSAMD_SCHED_LAUNCH(true, 16); else TSAMD_SCHED_LAUNCH(false, 16);
+  } else {
+    if (partial) TSAMD_SCHED_LAUNCH(true, 32); else TSAMD_SCHED_LAUNCH(false, 32);
+  }
 }
 
-// does a workgroup of it fit a compute unit (register budget)?
+// does a workgroup of it fit a compute unit (register budget)?  (worst case of the instantiations)
 int TSAMD_CAT(schedule_blocks_per_cu_k, TSAMD_K)() {
-  int nb = 0, nb2 = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ts_schedule<TSAMD_K, false>, kResidentBlock, 0) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, ts_schedule<TSAMD_K, true>, kResidentBlock, 0) != hipSuccess) return 0;
-  return nb < nb2 ? nb : nb2;
+  int worst = 1 << 30;
+  auto probe = [&](auto kernel) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kResidentBlock, 0) != hipSuccess) nb = 0;
+    worst = nb < worst ? nb : worst;
+  };
+  probe(ts_schedule<TSAMD_K, false, 0>);
+  probe(ts_schedule<TSAMD_K, true, 0>);
+  probe(ts_schedule<TSAMD_K, false, 8>);
+  probe(ts_schedule<TSAMD_K, true, 8>);
+  probe(ts_schedule<TSAMD_K, false, 16>);
+  probe(ts_schedule<TSAMD_K, true, 16>);
+  probe(ts_schedule<TSAMD_K, false, 32>);
+  probe(ts_schedule<TSAMD_K, true, 32>);
+  return worst;
 }
 
 }  // namespace tsamd

@@ -52,6 +52,11 @@ def main():
             eng.close()
             d.destroy_process_group()
             sys.exit(77)
+    if os.environ.get("TS_LAUNCH_MODE"):      # e.g. 0: one launch per pass although the shard qualifies for ts_schedule
+        eng.set_launch_mode(int(os.environ["TS_LAUNCH_MODE"]))
+    kps = eng.launch_info()["kernels_per_snp"]
+    if os.environ.get("TS_EXPECT_KPS"):       # which kernel sequence the test means to exercise
+        assert kps == int(os.environ["TS_EXPECT_KPS"]), f"kernels per SNP: {kps}"
     locs = np.random.default_rng(seed + 3).integers(0, l, size=nsnp).astype(np.uint32)
     eng.run_schedule(locs[:5])          # eager path
     eng.synchronize()
@@ -61,7 +66,7 @@ def main():
     full = tdist.gather_rows(eng.get_gamma(), n, d, ts.shard_range)
     cnt = tdist.gather_rows(eng.get_counts().astype(np.float64)[:, None], n, d, ts.shard_range)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), lam=eng.get_lambda(), gamma=full, cnt=cnt, its=np.array(its),
-             passes=eng.total_passes())
+             passes=eng.total_passes(), kps=kps)
     d.barrier()
     eng.close()
     d.barrier()

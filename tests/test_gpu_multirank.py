@@ -39,6 +39,8 @@ def _run_ranks(tmp_path, mode, world, n, l, k, seed, nsnp, extra_env=None, ok_co
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), TS_DEVICE=str(rank if distinct else 0), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if not distinct:
+            env["TSAMD_DEVICE_SHARE"] = str(world)   # the ranks' resident kernels (ts_schedule) must fit device 0 together
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), str(tmp_path), mode,
                                        str(n), str(l), str(k), str(seed), str(nsnp)],
@@ -117,6 +119,36 @@ def test_p2p_small_pass_caps(tmp_path, world, max_inner):
                      extra_env={"TS_MAX_INNER": str(max_inner), "TS_DELAY_RANK": "0", "TS_DELAY_US": "100"})
     orc, its = _oracle_run(n, l, k, seed, nsnp, online_iterations=max_inner)
     _assert_ranks_match(res, orc, its)
+
+
+@pytest.mark.parametrize("world,n,k,thresh,max_inner", [(2, 40_000, 8, None, None), (4, 70_000, 5, None, None),
+                                                        (2, 60_000, 8, 8.0, None), (3, 50_000, 3, None, 3),
+                                                        (8, 70_000, 8, None, None), (2, 300_000, 8, None, None)])
+def test_sharded_schedule_kernel_matches_oracle(tmp_path, world, n, k, thresh, max_inner):
+    """Shards of at least 8 workgroups, K <= 8: every rank runs the whole schedule as ONE launch (ts_schedule) whose
+    in-launch exchange spans the ranks -- group sums stored into every rank's buffer, each rank polls its own copy.
+    Against the oracle; replicated state bitwise equal on all ranks; with SNPs that stop after differing pass counts and
+    with a pass cap of 3.  The same shards with one launch per pass (TS_LAUNCH_MODE=0) must agree to rounding."""
+    l, seed, nsnp = 24, 77, 40
+    env, over = {"TS_EXPECT_KPS": "0"}, {}
+    if thresh is not None:
+        env["TS_CONV_THRESH"] = str(thresh)
+        over["meanchangethresh"] = thresh
+    if max_inner is not None:
+        env["TS_MAX_INNER"] = str(max_inner)
+        over["online_iterations"] = max_inner
+    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp, extra_env=env)
+    orc, its = _oracle_run(n, l, k, seed, nsnp, **over)
+    if thresh is not None:
+        assert len(set(its)) >= 2 and min(its) < 10, f"pass counts do not vary: {sorted(set(its))}"
+    _assert_ranks_match(res, orc, its)
+    assert all(int(r["kps"]) == 0 for r in res)
+    if world == 2 and thresh is None and n < 100_000:
+        (tmp_path / "pp").mkdir()
+        ref = _run_ranks(tmp_path / "pp", "p2p", world, n, l, k, seed, nsnp,
+                         extra_env={"TS_LAUNCH_MODE": "0", "TS_EXPECT_KPS": "10"})
+        assert rel_err(res[0]["lam"], ref[0]["lam"]) < 1e-11 and rel_err(res[0]["gamma"], ref[0]["gamma"]) < 1e-11
+        assert np.array_equal(res[0]["cnt"], ref[0]["cnt"])
 
 
 def test_rccl_two_ranks_matches_oracle(tmp_path):
