@@ -89,8 +89,11 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
     import oracle_py as op
     from terastructure_amd import dist as tdist
 
+    # three candidates: the RCCL all-reduce, peer-to-peer stores with one launch per pass ("p2p"), and ts_schedule with
+    # its in-launch exchange across the ranks ("p2p_schedule": one launch per rank and schedule; K <= 8 and shards of
+    # 8 ... 256 workgroups only)
     forced = os.environ.get("TSAMD_EXCHANGE", "auto").lower()
-    modes = [forced] if forced in ("rccl", "p2p") else ["rccl", "p2p"]
+    modes = [forced] if forced in ("rccl", "p2p", "p2p_schedule") else ["rccl", "p2p", "p2p_schedule"]
     l = 32
     sb, sc = shard
     beta = np.random.default_rng(7).uniform(0.05, 0.95, size=(l, k))
@@ -106,11 +109,17 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
             e.synth_genotypes(theta_shard, beta, seed=11)
             e.set_gamma(gamma_full[sb:sb + sc])
             try:
-                (tdist.bootstrap_p2p if mode == "p2p" else tdist.bootstrap_comm)(e, dist)
+                (tdist.bootstrap_comm if mode == "rccl" else tdist.bootstrap_p2p)(e, dist)
             except Exception as exc:  # noqa: BLE001 -- raised on every rank together
                 if rank == 0:
                     print(f"[bench] exchange self-test, {mode}: {exc}", file=sys.stderr, flush=True)
                 continue
+            whole = e.launch_info()["kernels_per_snp"] == 0   # (the same on every rank: it depends on the configuration only)
+            if mode == "p2p" and whole:
+                e.set_launch_mode(ts.LAUNCH_PER_PASS)
+            if mode == "p2p_schedule" and not whole:
+                report["valid"].pop(mode)
+                continue                                       # the shards do not qualify: not a candidate
             if want is None:  # the oracle's answer for the first 6 updates, once, on rank 0
                 cols = np.stack([e.download_bed(j) for j in range(l)])          # [l][shard bytes]
                 parts = gather_bytes(cols, dist, rank)
@@ -162,19 +171,21 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
             dist.barrier()
             e.close()
             dist.barrier()
-    if final.get("p2p") is not None and final.get("rccl") is not None:
-        d = max(rel_err(a, b_) for a, b_ in zip(final["p2p"], final["rccl"]))
-        td = torch.tensor([d], dtype=torch.float64)
-        dist.all_reduce(td, op=dist.ReduceOp.MAX)
-        report["p2p_vs_rccl_rel_err_260_updates"] = float(td.item())
-        if float(td.item()) > 1e-8:  # they disagree although both matched the oracle early on: trust neither
-            report["valid"]["p2p"] = report["valid"]["rccl"] = False
+    # candidates that matched the oracle after 6 updates must also agree with each other after 260
+    ok = [m for m in modes if final.get(m) is not None]
+    for i, a in enumerate(ok):
+        for b in ok[i + 1:]:
+            d = max(rel_err(x, y_) for x, y_ in zip(final[a], final[b]))
+            td = torch.tensor([d], dtype=torch.float64)
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+            report[f"{b}_vs_{a}_rel_err_260_updates"] = float(td.item())
+            if float(td.item()) > 1e-8:  # they disagree although both matched the oracle early on: trust neither
+                report["valid"][a] = report["valid"][b] = False
     rates = report["updates_per_s"]
     chosen = None
-    if report["valid"].get("p2p") and (not report["valid"].get("rccl") or rates["p2p"] >= rates["rccl"]):
-        chosen = "p2p"
-    elif report["valid"].get("rccl"):
-        chosen = "rccl"
+    for m in ("rccl", "p2p", "p2p_schedule"):   # (later ones win ties: fewer launches)
+        if report["valid"].get(m) and (chosen is None or rates[m] >= rates[chosen]):
+            chosen = m
     report["chosen"] = chosen
     if rank == 0:
         print(f"[bench] exchange self-test: {json.dumps(report)}", file=sys.stderr, flush=True)
@@ -188,6 +199,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "TSAMD_BENCH_DEVICE" in os.environ:  # development only: several ranks on one GPU
         local_rank = int(os.environ["TSAMD_BENCH_DEVICE"])
+        os.environ.setdefault("TSAMD_DEVICE_SHARE", str(world))  # their resident kernels must fit that GPU together
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -257,7 +269,9 @@ def main():
 
         err = None
         try:
-            (tdist.bootstrap_p2p if exchange == "p2p" else tdist.bootstrap_comm)(eng, dist)
+            (tdist.bootstrap_comm if exchange == "rccl" else tdist.bootstrap_p2p)(eng, dist)
+            if exchange == "p2p" and eng.launch_info()["kernels_per_snp"] == 0:
+                eng.set_launch_mode(ts.LAUNCH_PER_PASS)   # (the in-launch exchange did not pass, or was slower)
         except Exception as exc:  # noqa: BLE001
             err = exc
         fail_together(err is None, dist, f"exchange bootstrap: {err}")
@@ -362,12 +376,14 @@ def main():
         # to for this measurement only)
         per_snp = None
         if mode == "schedule":
-            eng.set_launch_mode(ts.LAUNCH_PER_SNP)
+            # (a sharded context has no launch-per-SNP mode: its other sequence is one launch per pass)
+            sub = ts.LAUNCH_PER_SNP if world == 1 else ts.LAUNCH_PER_PASS
+            eng.set_launch_mode(sub)
             try:
                 pr, _ = profiled(min(args.steps, 300))
             finally:
                 eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
-            sub_mode = "snp" if eng.cfg.max_inner > 2 else "pass"
+            sub_mode = "snp" if (world == 1 and eng.cfg.max_inner > 2) else "pass"
         else:
             pr, _ = profiled(min(args.steps, 300))
             sub_mode = mode

@@ -247,7 +247,10 @@ int tsamd_probe_stream(tsamd_ctx *ctx, uint32_t reps, double *read_us, double *r
 int tsamd_launch_info(tsamd_ctx *ctx, uint32_t *kernels_per_snp, uint32_t *plain_grid, uint32_t *first_grid);
 /* Selects how the context launches from now on: one kernel per pass, one resident kernel for the plain passes of
  * a SNP, or one kernel per schedule.  tsamd_create picks the highest mode the context qualifies for; this call
- * can lower it and raise it again (TSAMD_EUNSUPPORTED above what the context qualifies for).  All modes give the
+ * can lower it and raise it again (TSAMD_EUNSUPPORTED above what the context qualifies for).  A sharded context
+ * (tsamd_p2p_connect / _connect_local) qualifies for TSAMD_LAUNCH_PER_SCHEDULE when k <= 8, nodekappa == 0.5,
+ * world <= 8 and every rank's shard fills 8 ... 256 workgroups (the in-launch exchange then spans the ranks; ranks
+ * that share a device: TSAMD_DEVICE_SHARE=<ranks> in the environment), never for TSAMD_LAUNCH_PER_SNP.  All modes give the
  * same results to rounding (the order in which the workgroups' partial rows are added differs), and each mode is
  * bitwise reproducible and independent of how a schedule is cut into calls.  Synchronises the stream. */
 #define TSAMD_LAUNCH_PER_PASS 0
