@@ -1372,6 +1372,10 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   uint32_t prev_loc = sloc, prev_hol = shol, prev_iters = siters;
   bool w_dirty = false;
   uint32_t xcount = 0u;  // exchanges of this launch
+#ifdef TSAMD_SCHED_RAMP
+  unsigned long long ramp_mark = wall_clock64();
+  uint32_t ramp_idx = 0u;
+#endif
 #ifdef TSAMD_SCHED_TIME  // diagnostic build (tools/variant.sh): where a SNP's time goes, 10 ns ticks, workgroup 0
   unsigned long long tk_gamma = 0, tk_first = 0, tk_rest = 0, tk_xchg = 0, tk_head = 0, tk_tail = 0, tk_mark = wall_clock64();
   const unsigned long long tk_start = tk_mark;
@@ -1699,6 +1703,19 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     prev_iters = iters;
     __syncthreads();
     TSAMD_TK(tk_tail);
+#ifdef TSAMD_SCHED_RAMP  // diagnostic: time per SNP over ranges of the launch (does a launch start slow?)
+    if (blockIdx.x == 0 && tid == 0) {
+      const uint32_t marks[8] = {5u, 20u, 50u, 100u, 200u, 500u, 1000u, 2000u};
+      for (int q = 0; q < 8; ++q)
+        if (idx + 1u == marks[q]) {
+          const unsigned long long now = wall_clock64();
+          printf("ts_schedule ramp: SNPs up to %u: %.2f us per SNP in this range (launch of %u)\n", marks[q],
+                 (now - ramp_mark) * 0.01 / (double)(marks[q] - ramp_idx), n_sched);
+          ramp_mark = now;
+          ramp_idx = marks[q];
+        }
+    }
+#endif
   }
 
   // ---- end of the launch: the weights go back to memory, the state to the next call -------------
