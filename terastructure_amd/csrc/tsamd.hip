@@ -1080,7 +1080,8 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   if (!stage.first) {
     size_t cap = 1024;
     while (cap < n) cap *= 2;
-    HIP_TRY(c, hipHostMalloc((void **)&stage.first, cap * sizeof(uint32_t), hipHostMallocDefault));
+    // (portable + mapped: ts_schedule reads the entries straight from this buffer, on whichever device the context uses)
+    HIP_TRY(c, hipHostMalloc((void **)&stage.first, cap * sizeof(uint32_t), hipHostMallocPortable | hipHostMallocMapped));
     stage.second = cap;
   }
   c->sched_busy.push_back(stage);

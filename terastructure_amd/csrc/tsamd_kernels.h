@@ -1378,6 +1378,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
 #endif
 #ifdef TSAMD_SCHED_TIME  // diagnostic build (tools/variant.sh): where a SNP's time goes, 10 ns ticks, workgroup 0
   unsigned long long tk_gamma = 0, tk_first = 0, tk_rest = 0, tk_xchg = 0, tk_head = 0, tk_tail = 0, tk_mark = wall_clock64();
+  unsigned long long tk_fold = 0, tk_epi = 0;
   const unsigned long long tk_start = tk_mark;
 #define TSAMD_TK(acc)                         \
   do {                                        \
@@ -1438,6 +1439,9 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   auto finish_pass = [&]() -> bool {
     fresh();
     const uint32_t lane = tid & 63u, wave = tid >> 6;
+#ifdef TSAMD_SCHED_TIME
+    const unsigned long long tf0 = wall_clock64();
+#endif
     {
       using Fold = WaveFold<2 * KT>;
       double v[Fold::P];
@@ -1456,6 +1460,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     __syncthreads();
 #ifdef TSAMD_SCHED_TIME
     const unsigned long long tx0 = wall_clock64();
+    tk_fold += tx0 - tf0;
 #endif
     xcount += 1u;
     const uint32_t tag = xseq0 + xcount;
@@ -1506,12 +1511,16 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     }
     __syncthreads();
 #ifdef TSAMD_SCHED_TIME
-    tk_xchg += wall_clock64() - tx0;
+    const unsigned long long te0 = wall_clock64();
+    tk_xchg += te0 - tx0;
 #endif
     if (!s_alive) return false;
     if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);
     __syncthreads();
     complete = epilogue_complete(p, iters, J, s_diff);
+#ifdef TSAMD_SCHED_TIME
+    tk_epi += wall_clock64() - te0;
+#endif
     return true;
   };
 
@@ -1756,8 +1765,8 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
 #ifdef TSAMD_SCHED_TIME
       if (n_sched >= 16u)
         printf("ts_schedule n=%u exchanges=%u | per SNP (us): head %.2f gamma %.2f first pass %.2f later passes %.2f tail %.2f | "
-               "in exchanges %.2f | whole launch %.1f us\n", n_sched, xcount, tk_head * 0.01 / n_sched, tk_gamma * 0.01 / n_sched,
-               tk_first * 0.01 / n_sched, tk_rest * 0.01 / n_sched, tk_tail * 0.01 / n_sched, tk_xchg * 0.01 / n_sched,
+               "in exchanges %.2f, in folds %.2f, in epilogues %.2f | whole launch %.1f us\n", n_sched, xcount, tk_head * 0.01 / n_sched, tk_gamma * 0.01 / n_sched,
+               tk_first * 0.01 / n_sched, tk_rest * 0.01 / n_sched, tk_tail * 0.01 / n_sched, tk_xchg * 0.01 / n_sched, tk_fold * 0.01 / n_sched, tk_epi * 0.01 / n_sched,
                (wall_clock64() - tk_start) * 0.01);
 #endif
     }
