@@ -35,11 +35,11 @@ def kb(fetch, write):
 N = 1_000_000
 records = []
 f, w = maxima(f"{D}/r02_k8_pmc_fetch_size.txt"), maxima(f"{D}/r02_k8_pmc_write_size.txt")
-fs, ws = pick(f, "ts_schedule<8>"), pick(w, "ts_schedule<8>")
+fs, ws = pick(f, "ts_schedule<8"), pick(w, "ts_schedule<8")
 if fs is not None:
     upd = 200  # tools/profile_round.sh: the largest launch of the counter runs is the 200-update schedule
     records.append({
-        "mode": "schedule", "kernel": "ts_schedule<8>", "n": N, "k": 8, "n_gpus": 1, "updates_in_launch": upd,
+        "mode": "schedule", "kernel": "ts_schedule<8,false,0>", "n": N, "k": 8, "n_gpus": 1, "updates_in_launch": upd,
         "FETCH_SIZE_KB_max": fs, "WRITE_SIZE_KB_max": ws,
         "hbm_bytes_per_launch": kb(fs, ws), "hbm_bytes_per_update": kb(fs, ws) / upd,
         "note": ("per update the kernel streams the gamma rows and c_n of every second item (K = 8: the other half stays in "
