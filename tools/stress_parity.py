@@ -1,4 +1,4 @@
-"""Randomised parity stress (not part of the test suite): many (n, k, missing rate, pass cap)
+"""Randomised parity stress (not part of the test suite): many (n, k, missing rate, pass cap, launch mode)
 combinations, device vs oracle: inner pass counts exactly, lambda / gamma to 1e-9.
 python tools/stress_parity.py [cases] [seed]"""
 import os, sys
@@ -13,7 +13,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for c in range(cases):
-    n = int(rng.choice([1, 7, 64, 200, 513, 1000, 2999, 5000, 12000]))
+    n = int(rng.choice([1, 7, 64, 200, 513, 1000, 2999, 5000, 12000, 70001, 150000]))
     k = int(rng.integers(1, 41))
     l = 12
     miss = float(rng.choice([0.0, 0.02, 0.3]))
@@ -24,7 +24,13 @@ for c in range(cases):
     g = init_gamma(n, k, seed + 1)
     if rng.random() < 0.2:
         g = g * 10.0 ** rng.uniform(-2, 3, size=g.shape)
-    eng = ts.Engine(n, l, k, max_inner=cap); orc = op.Oracle(n, l, k, online_iterations=cap)
+    eng = ts.Engine(n, l, k, max_inner=cap); orc = op.Oracle(n, l, k, online_iterations=cap, nthreads=8 if n > 20000 else 1)
+    mode = int(rng.integers(0, 4))   # 3: whatever tsamd_create chose
+    if mode < 3:
+        try:
+            eng.set_launch_mode(mode)
+        except ts.TsamdError:
+            mode = 3
     eng.upload_bed(payload); orc.load_bed_payload(payload); eng.set_gamma(g); orc.set_gamma(g)
     for loc in rng.choice(l, size=2, replace=False):
         cand = np.nonzero(y[loc] != 3)[0]
@@ -50,6 +56,6 @@ for c in range(cases):
     ok = ok and el < 1e-9 and eg < 1e-9 and np.array_equal(eng.get_counts(), orc.c_indiv())
     if not ok:
         bad += 1
-        print(f"MISMATCH case {c}: n={n} k={k} miss={miss} cap={cap} seed={seed} passes {eng.total_passes()} vs {sum(its_o)} lambda {el:.2e} gamma {eg:.2e}", flush=True)
+        print(f"MISMATCH case {c}: n={n} k={k} miss={miss} cap={cap} mode={mode} seed={seed} passes {eng.total_passes()} vs {sum(its_o)} lambda {el:.2e} gamma {eg:.2e}", flush=True)
     eng.close(); orc.close()
 print(f"{cases} cases, {bad} mismatches")
