@@ -461,6 +461,8 @@ def main():
                     "algorithmic_bytes_per_update": alg_bytes / upd,
                     "moved_bytes_per_update": moved,
                     "moved_floor_us_per_update": round(moved / (HBM_PEAK_GBS * 1e9) * 1e6, 3),
+                    "moved_GBps": round(moved * upd / launch_s / 1e9, 1),   # what the kernel really asks of memory ...
+                    "moved_frac": round(moved * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),  # ... as a fraction of the HBM peak
                     "ceiling_note": ("algorithmic bytes = the reference's dataflow (every pass re-reads the N x K weights, the gamma step "
                                      "reads and writes weights and gamma).  ts_schedule keeps the weights in registers, so per update it "
                                      "moves only moved_bytes_per_update (gamma read + write, c_n, one 2-bit column; `traffic` is the "
