@@ -1259,14 +1259,16 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
 
 
 // ---------------------------------------------------------------------------
-// ts_schedule<K>: a WHOLE schedule in one launch (single GPU, K <= 8, shards up to ~1M individuals:
-// same residency conditions as ts_resident).  The weights w stay in registers from the first SNP
-// to the last: the gamma step of a SNP reads and writes gamma (and c_n) only and overwrites the
-// registers with the new weights, every pass runs from registers, and every pass ends with the
-// in-launch exchange of the partial rows (ResXchg).  Per SNP the memory traffic drops from
-// (I + 3) 8NK to 16NK (gamma read + write); w is written back once, at the end of the launch.
-// Same semantics as the launch-per-pass state machine: starts from the State the previous call
-// left (its last SNP complete, its gamma step possibly pending) and leaves such a State.
+// ts_schedule<K, PARTIAL, WR>: a WHOLE schedule in one launch (K <= 8, shards up to ~1M individuals per GPU: the
+// residency conditions of ts_resident; one GPU, or -- WR > 0 -- one launch per rank of a sharded run).  The weights w
+// stay in registers from the first SNP to the last: the gamma step of a SNP reads and writes gamma (and c_n) only --
+// half of it from LDS at K = 8 -- and overwrites the registers with the new weights, every pass runs from registers,
+// and every pass ends with the in-launch exchange of the partial rows (ResXchg; level 2 across the ranks through
+// Xchg::res_sums when sharded).  Per SNP the memory traffic drops from (I + 3) 8NK to 8NK .. 16NK (gamma read +
+// write); w and the LDS-resident gamma are written back once, at the end of the launch.
+// Same semantics as the launch-per-pass state machine: starts from the State the previous call left (its last SNP
+// complete, its gamma step possibly pending) and leaves such a State.  PARTIAL: skip the item bodies no thread of
+// the workgroup owns (small shards).  WR: row pairs per lane of the cross-rank level 2 (0: single GPU).
 // ts_schedule: how many of a thread's items keep their gamma in LDS (per item: K rows x 16 bytes + c_n for 256 threads;
 // 4 KB of the 160 KB stay free for the small arrays), and which streamed item follows item t (items = none)
 constexpr int sched_lds_items(int k, int items) {
