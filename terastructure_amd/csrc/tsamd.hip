@@ -691,8 +691,8 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   c->sched_cap = 1024;
   CREATE_TRY(hipMalloc((void **)&c->d_sched, c->sched_cap * sizeof(uint32_t)));
 
-  CREATE_TRY(hipHostMalloc((void **)&c->h_error, sizeof(unsigned long long), hipHostMallocDefault));
-  *c->h_error = 0ull;
+  CREATE_TRY(hipHostMalloc((void **)&c->h_error, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  c->h_error[0] = c->h_error[1] = 0ull;  // [0] error tag, [1] inner passes of the last completed SNP (DevParams::host_error)
   p.host_error = c->h_error;
   if (c->resident) {
     CREATE_TRY(hipMalloc((void **)&c->res, sizeof(ResXchg)));
@@ -1227,7 +1227,7 @@ int tsamd_snp_update(tsamd_ctx *c, uint32_t loc, int hol_mode, uint32_t *inner_i
   if (int rc = tsamd_run_schedule(c, &loc, 1, hol_mode)) return rc;
   if (int rc = tsamd_synchronize(c)) return rc;
   if (inner_iters) {
-    HIP_TRY(c, hipMemcpy(inner_iters, &c->p.ctl->last_iters, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *inner_iters = (uint32_t) * (volatile unsigned long long *)(c->h_error + 1);  // (written by the kernel that completed the SNP)
   }
   return TSAMD_OK;
 }

@@ -131,8 +131,9 @@ struct DevParams {
   uint32_t xchg_rank;
   Xchg *xchg;            // this rank's buffer
   Xchg *peers[kMaxRanks]; // every rank's buffer as mapped into this process (peers[xchg_rank] == xchg)
-  unsigned long long *host_error;  // pinned host word: a bounded in-kernel wait that gives up also writes its tag here,
-                                   // so tsamd_synchronize sees it without a device-to-host copy
+  unsigned long long *host_error;  // pinned host words.  [0]: a bounded in-kernel wait that gives up also writes its tag here,
+                                   // so tsamd_synchronize sees it without a device-to-host copy; [1]: the inner passes of
+                                   // the most recently completed SNP (Ctl::last_iters), so tsamd_snp_update needs no copy either
   ResXchg *res;              // resident plain-pass kernel: its exchange buffer (NULL: launch per pass)
   uint32_t xchg_test_delay;  // test hook (TSAMD_TEST_XCHG_DELAY_US): stall between flag wait and row reads, 10 ns ticks
   uint32_t xchg_test_noguard; // test hook (TSAMD_TEST_XCHG_NOGUARD): skip the slot-reuse guard (to show the test sees the hazard)

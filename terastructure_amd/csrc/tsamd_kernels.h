@@ -150,6 +150,7 @@ __device__ __forceinline__ void publish_complete(const DevParams &p, Ctl *ctl, c
   }
   if (tid == 0) {
     ctl->last_iters = S->iters;
+    if (p.host_error) __hip_atomic_store(p.host_error + 1, (unsigned long long)S->iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     ctl->total_passes += (unsigned long long)S->iters;
     ctl->pass_hist[min(S->iters, (uint32_t)TSAMD_PASS_HIST_BINS - 1u)] += 1ull;
     if (write_state) {
@@ -178,6 +179,7 @@ __device__ __forceinline__ void publish_complete_v(const DevParams &p, Ctl *ctl,
   }
   if (tid == 0) {
     ctl->last_iters = iters;
+    if (p.host_error) __hip_atomic_store(p.host_error + 1, (unsigned long long)iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     ctl->total_passes += (unsigned long long)iters;
     ctl->pass_hist[min(iters, (uint32_t)TSAMD_PASS_HIST_BINS - 1u)] += 1ull;
     W->idx = idx;
@@ -1694,6 +1696,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       }
       if (tid == 0) {
         ctl->last_iters = iters;
+        if (p.host_error) __hip_atomic_store(p.host_error + 1, (unsigned long long)iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         ctl->total_passes += (unsigned long long)iters;
         ctl->pass_hist[min(iters, (uint32_t)TSAMD_PASS_HIST_BINS - 1u)] += 1ull;
       }
