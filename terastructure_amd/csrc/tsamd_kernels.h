@@ -338,87 +338,6 @@ __device__ __forceinline__ void gamma_to_w(const double (&g)[KT], double (&w)[KT
   for (int k = 0; k < KT; ++k) w[k] = z[k] * exp_nonpos(a[k] - amax);
 }
 
-// The same arithmetic, operation for operation, written stage by stage across the populations: the K recurrences
-// of every stage are independent, and a SIMD that runs a single wave (ts_schedule) has nothing else to issue
-// while one dependent fp64 operation follows another.
-template <int KT>
-__device__ __forceinline__ void gamma_to_w_staged(const double (&g)[KT], double (&w)[KT]) {
-  double z[KT], a[KT], num[KT], den[KT], q[KT];
-#pragma unroll
-  for (int k = 0; k < KT; ++k) {
-    q[k] = g[k] * (g[k] + 9.0);
-    num[k] = 1.0;
-    den[k] = q[k];
-  }
-#pragma unroll
-  for (int i = 1; i < 5; ++i) {
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const double qi = q[k] + (double)(i * (9 - i));
-      num[k] = fma(num[k], qi, den[k]);
-      den[k] *= qi;
-    }
-  }
-  double inv[KT], f[KT], rz[KT], r[KT], t[KT];
-#pragma unroll
-  for (int k = 0; k < KT; ++k) {
-    z[k] = g[k] + 10.0;
-    inv[k] = den[k] * z[k];
-  }
-  {  // fast_rcp, stage by stage
-    double rr[KT], e[KT];
-#pragma unroll
-    for (int k = 0; k < KT; ++k) rr[k] = __builtin_amdgcn_rcp(inv[k]);
-#pragma unroll
-    for (int k = 0; k < KT; ++k) e[k] = fma(-inv[k], rr[k], 1.0);
-#pragma unroll
-    for (int k = 0; k < KT; ++k) rr[k] = fma(rr[k], e[k], rr[k]);
-#pragma unroll
-    for (int k = 0; k < KT; ++k) e[k] = fma(-inv[k], rr[k], 1.0);
-#pragma unroll
-    for (int k = 0; k < KT; ++k) inv[k] = fma(rr[k], e[k], rr[k]);
-  }
-#pragma unroll
-  for (int k = 0; k < KT; ++k) {
-    r[k] = (fma(2.0, g[k], 9.0) * num[k]) * (z[k] * inv[k]);
-    rz[k] = den[k] * inv[k];
-    f[k] = rz[k] * rz[k];
-    t[k] = -1.0 / 12.0;
-  }
-  constexpr double kB[6] = {691.0 / 32760.0, -1.0 / 132.0, 1.0 / 240.0, -1.0 / 252.0, 1.0 / 120.0, -1.0 / 12.0};
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-#pragma unroll
-    for (int k = 0; k < KT; ++k) t[k] = fma(f[k], t[k], kB[j]);
-  }
-  double amax = -1.0e300;
-#pragma unroll
-  for (int k = 0; k < KT; ++k) {
-    a[k] = fma(f[k], t[k], -0.5 * rz[k]) - r[k];
-    amax = fmax(amax, a[k]);
-  }
-  // exp_nonpos(a - amax), stage by stage
-  double n[KT], rr[KT], pp[KT];
-#pragma unroll
-  for (int k = 0; k < KT; ++k) {
-    const double d = a[k] - amax;
-    n[k] = __builtin_rint(d * 1.4426950408889634074);
-    rr[k] = fma(n[k], -6.93147180369123816490e-01, d);
-    rr[k] = fma(n[k], -1.90821492927058770002e-10, rr[k]);
-    pp[k] = 1.0 / 6227020800.0;
-  }
-  constexpr double kE[13] = {1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0,
-                             1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,      1.0 / 6.0,      0.5,           1.0,
-                             1.0};
-#pragma unroll
-  for (int j = 0; j < 13; ++j) {
-#pragma unroll
-    for (int k = 0; k < KT; ++k) pp[k] = fma(pp[k], rr[k], kE[j]);
-  }
-#pragma unroll
-  for (int k = 0; k < KT; ++k) w[k] = z[k] * __builtin_amdgcn_ldexp(pp[k], (int)n[k]);
-}
-
 // SVI step for one individual (update_gamma + update_rho_indiv,
 // src/snpsamplinge.cc:688-719) using phi recomputed from the weights w and the
 // exp(Elogbeta) of the previous SNP's LAST pass (sb0/sb1).
@@ -1628,7 +1547,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
             const double e = c0 * (wx[k] * sbv[2 * k]) + c1 * (wx[k] * sbv[2 * k + 1]);
             gx[k] += rho * (p.alpha + p.gamma_scale * e - gx[k]);
           }
-          gamma_to_w_staged<KT>(gx, wx);
+          gamma_to_w<KT>(gx, wx);
           const uint32_t cnew = ok ? cv.x + 1u : cv.x;
           cv.x = cv.y;
           cv.y = cnew;
