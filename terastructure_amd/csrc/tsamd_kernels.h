@@ -113,7 +113,10 @@ __device__ __forceinline__ void epilogue_values(const DevParams &p, double lt, d
 __device__ __forceinline__ bool epilogue_complete(const DevParams &p, uint32_t iters, uint32_t J, const double *s_diff) {
   double d = 0.0;
   for (uint32_t jj = 0; jj < J; ++jj) d += s_diff[jj];
-  d /= (double)J;
+  if ((J & (J - 1u)) == 0u)
+    d *= 1.0 / (double)J;  // (a power of two: the same bits as the division, without its fifteen instructions)
+  else
+    d /= (double)J;
   return d < p.thresh || iters >= p.max_inner;
 }
 
