@@ -102,6 +102,9 @@ struct tsamd_ctx {
   uint8_t *d_hy = nullptr;
   double *d_hterms = nullptr;
   size_t held_cap = 0;
+  uint32_t *d_fold_ids = nullptr;  // scratch of tsamd_set_heldout
+  uint8_t *d_fold_orig = nullptr;
+  size_t fold_cap = 0;
   HeldReq *d_hreq = nullptr;
   double *d_hsums = nullptr;
   size_t hreq_cap = 0;
@@ -580,6 +583,8 @@ void tsamd_destroy(tsamd_ctx *c) {
   hipFree(c->d_hy);
   hipFree(c->d_hterms);
   hipFree(c->d_hreq);
+  hipFree(c->d_fold_ids);
+  hipFree(c->d_fold_orig);
   hipFree(c->d_hsums);
   if (c->h_stage) hipHostFree(c->h_stage);
   for (auto &b : c->sched_busy) hipHostFree(b.first);
@@ -903,24 +908,42 @@ int tsamd_set_heldout(tsamd_ctx *c, uint32_t loc, const uint32_t *indivs, uint32
   if (count && !indivs) return fail(c, TSAMD_EINVAL, "null indivs");
   HeldLoc &h = c->held[loc];
   c->held_dirty = true;
+  // the new entries of this shard, ascending and without duplicates (the reference's map has one entry per
+  // (individual, location); N/100 individuals per location at config 4: no quadratic searches)
   std::vector<uint32_t> ids;
+  ids.reserve(count);
   for (uint32_t i = 0; i < count; ++i) {
     if (indivs[i] >= c->cfg.n) return fail(c, TSAMD_EINVAL, "individual %u >= n", indivs[i]);
     if (indivs[i] < c->n_begin || indivs[i] >= c->n_begin + c->n_local) continue;
-    const uint32_t lid = indivs[i] - c->n_begin;
-    if (std::find(h.local_ids.begin(), h.local_ids.end(), lid) != h.local_ids.end()) continue;
-    if (std::find(ids.begin(), ids.end(), lid) != ids.end()) continue;
-    ids.push_back(lid);
+    ids.push_back(indivs[i] - c->n_begin);
   }
+  std::sort(ids.begin(), ids.end());
+  ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+  if (!h.local_ids.empty())  // (kept ascending, see below)
+    ids.erase(std::remove_if(ids.begin(), ids.end(),
+                             [&](uint32_t lid) { return std::binary_search(h.local_ids.begin(), h.local_ids.end(), lid); }),
+              ids.end());
   if (ids.empty()) {
     if (h.local_ids.empty()) c->held.erase(loc);
     return TSAMD_OK;
   }
   HIP_TRY(c, hipSetDevice(c->dev));
-  uint32_t *d_ids = nullptr;
-  uint8_t *d_orig = nullptr;
-  HIP_TRY(c, hipMalloc((void **)&d_ids, ids.size() * sizeof(uint32_t)));
-  HIP_TRY(c, hipMalloc((void **)&d_orig, ids.size()));
+  // persistent scratch (ids in, original 2-bit codes out): no allocation per call
+  if (ids.size() > c->fold_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipFree(c->d_fold_ids);
+    hipFree(c->d_fold_orig);
+    c->d_fold_ids = nullptr;
+    c->d_fold_orig = nullptr;
+    c->fold_cap = 0;
+    size_t cap = 4096;
+    while (cap < ids.size()) cap *= 2;
+    HIP_TRY(c, hipMalloc((void **)&c->d_fold_ids, cap * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_fold_orig, cap));
+    c->fold_cap = cap;
+  }
+  uint32_t *d_ids = c->d_fold_ids;
+  uint8_t *d_orig = c->d_fold_orig;
   std::vector<uint8_t> orig(ids.size());
   hipError_t e = hipMemcpyAsync(d_ids, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
@@ -929,8 +952,6 @@ int tsamd_set_heldout(tsamd_ctx *c, uint32_t loc, const uint32_t *indivs, uint32
     e = hipMemcpyAsync(orig.data(), d_orig, ids.size(), hipMemcpyDeviceToHost, c->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(d_ids);
-  hipFree(d_orig);
   if (e != hipSuccess) return fail(c, TSAMD_EHIP, "set_heldout: %s", hipGetErrorString(e));
   static const uint8_t dec[4] = {0, 3, 1, 2};
   for (size_t i = 0; i < ids.size(); ++i) {
