@@ -472,6 +472,17 @@ def main():
                                      "the in-launch exchange of the partial rows (two dependent memory round trips per pass).  "
                                      "launch_per_snp holds the kernels of the launch-per-SNP sequence on the same data (the default "
                                      "mode for K > 8, sharded runs and larger shards), measured right after."),
+                    # the other roofline: fp64 vector arithmetic (no MFMA on this path).  Flops of the kernel's own formulation,
+                    # FMA = 2: a sweep is 8K + 20 per individual (two K-term normalisers, two reciprocals, 2K accumulations per
+                    # parent), the gamma step 124K + 30 (normalisers 4K, update 12K, exp(psi) 108K per individual)
+                    "fp64_valu": {
+                        "flops_per_update": (ran / nsteps) * sc * (8.0 * k + 20.0) + sc * (124.0 * k + 30.0),
+                        "achieved_TFLOPs": round(((ran / nsteps) * sc * (8.0 * k + 20.0) + sc * (124.0 * k + 30.0)) * upd / launch_s / 1e12, 2),
+                        "peak_TFLOPs": 78.6,
+                        "frac": round(((ran / nsteps) * sc * (8.0 * k + 20.0) + sc * (124.0 * k + 30.0)) * upd / launch_s / 1e12 / 78.6, 4),
+                        "note": ("MI355X fp64 vector peak 78.6 TFLOP/s (half the 157.3 TFLOP/s fp32 vector rate of MI355X_MICROARCH.md); "
+                                 "tools/fma_probe reaches 62.5 TFLOP/s with one wave per SIMD, the occupancy this kernel runs at"),
+                    },
                     "launch_per_snp": per_snp,
                     "first_pass": None if per_snp is None else per_snp["first_pass"],
                     "probe_read_us": None if read_us is None else round(read_us, 3),
