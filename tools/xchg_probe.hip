@@ -41,12 +41,27 @@ __device__ __forceinline__ u64 get(const u64 *g) { return __hip_atomic_load(g, _
 
 // L2 poll: N atomic ORs of 0 in flight (they execute at the XCD's L2; a workgroup-scope LOAD may be served by the
 // CU's own L1 and never see another CU's store, and the compiler turns an idempotent relaxed RMW back into a load)
+// -DL2MODE=1 / 2: instead, invalidate the CU's L1 (buffer_inv sc0 / sc1) and poll with plain loads; 3: plain loads with nt
+#ifndef L2MODE
+#define L2MODE 0
+#endif
 __device__ __forceinline__ void l2_issue(u64 &x, const u64 *addr) {
+#if L2MODE == 0
   const u64 zero = 0ull;
   asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0" : "=&v"(x) : "v"(addr), "v"(zero) : "memory");
+#elif L2MODE == 3
+  asm volatile("global_load_dwordx2 %0, %1, off nt" : "=&v"(x) : "v"(addr) : "memory");
+#else
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(x) : "v"(addr) : "memory");
+#endif
 }
 template <int N>
 __device__ __forceinline__ void l2_poll(const u64 *base, unsigned lane, u64 (&x)[N]) {
+#if L2MODE == 1
+  asm volatile("buffer_inv sc0" ::: "memory");
+#elif L2MODE == 2
+  asm volatile("buffer_inv sc1" ::: "memory");
+#endif
 #pragma unroll
   for (int i = 0; i < N; ++i) l2_issue(x[i], base + lane + 64 * i);
   if constexpr (N == 16)
@@ -58,6 +73,9 @@ __device__ __forceinline__ void l2_poll(const u64 *base, unsigned lane, u64 (&x)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]) : : "memory");
 }
 
+// diagnostics (-DPOLLSTATS): polls and 10 ns ticks spent in the sweeps of level 1 (index 0) and level 2 (index 1), summed
+// over a launch by workgroup 0 (a leader) and workgroup 9 (a member)
+__device__ unsigned long long g_polls[2][2], g_ticks[2][2];
 // one wave: re-read N granules per lane (index lane + 64 i) until every tag == tag
 // done (variant 3): several waves of the workgroup poll the same granules out of phase (stagger ticks apart);
 // the first one to see them complete posts the tag in LDS and the others leave (return value 2)
@@ -84,7 +102,13 @@ __device__ __forceinline__ int sweep(const u64 *base, unsigned tag, unsigned (&v
       v[i] = (unsigned)x[i];
       ok &= (unsigned)(x[i] >> 32) == tag;
     }
+#ifdef POLLSTATS
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 9)) atomicAdd(&g_polls[blockIdx.x == 9][N == 4], 1ull);
+#endif
     if (__all(ok)) {
+#ifdef POLLSTATS
+      if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 9)) atomicAdd(&g_ticks[blockIdx.x == 9][N == 4], wall_clock64() - t0);
+#endif
       if (done) *done = tag;
       return 1;
     }
@@ -160,7 +184,10 @@ __global__ __launch_bounds__(512) void probe(Xb *xb, int passes, unsigned tag0, 
     if (wave < kPollers && (VAR != 2 || m == 0)) {
       unsigned v[4];  // lane l: granule c = l % 32 of groups 2 i + (l >= 32)
       const u64 *src = VAR == 7 ? &xb->rep[p & 1][blockIdx.x % stagger_ticks][0] : &xb->sums[p & 1][0][0];
-      const int r2 = sweep<4>(src, tag, v, &xb->abort_word, VAR == 3 ? &s_done[1] : nullptr, VAR == 3 ? wave * stagger_ticks : 0u);
+      // VAR == 9: nobody polls level 2 before it can be there: members wait (stagger_ticks & 0xffff) ticks after their own
+      // store, leaders (stagger_ticks >> 16) ticks after theirs -- fewer useless polls hammering the 2 KB of group sums
+      const unsigned quiet = VAR == 9 ? (m != 0 ? (stagger_ticks & 0xffffu) : (stagger_ticks >> 16)) : VAR == 3 ? wave * stagger_ticks : 0u;
+      const int r2 = sweep<4>(src, tag, v, &xb->abort_word, VAR == 3 ? &s_done[1] : nullptr, quiet);
       alive = r2 != 0 && alive;
       double s = 0.0;
 #pragma unroll
@@ -195,6 +222,8 @@ __global__ __launch_bounds__(512) void probe(Xb *xb, int passes, unsigned tag0, 
   }
 }
 
+// variants 9 ..: (leader quiet ticks << 16) | member quiet ticks, 10 ns each
+static const unsigned g_quiet[] = {100u, 140u, 170u, 200u, (30u << 16) | 140u, (30u << 16) | 170u, (50u << 16) | 170u, (50u << 16) | 200u};
 int main(int argc, char **argv) {
   Xb *xb;
   double *out;
@@ -202,6 +231,7 @@ int main(int argc, char **argv) {
   // argv[1]: 0 = hipMalloc (default), 1 = fine-grained, 2 = uncached device memory for the exchange buffer
   const int kind = argc > 1 ? atoi(argv[1]) : 0;
   const int max_var = argc > 2 ? atoi(argv[2]) : 9;
+  const int min_var = argc > 3 ? atoi(argv[3]) : 0;
   if (kind == 0) CK(hipMalloc(&xb, sizeof(Xb)));
   if (kind == 1) CK(hipExtMallocWithFlags((void **)&xb, sizeof(Xb), hipDeviceMallocFinegrained));
   if (kind == 2) CK(hipExtMallocWithFlags((void **)&xb, sizeof(Xb), hipDeviceMallocUncached));
@@ -217,14 +247,16 @@ int main(int argc, char **argv) {
     if (var == 1) hipLaunchKernelGGL(probe<1>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, 0u);
     if (var == 2) hipLaunchKernelGGL(probe<2>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, 0u);
     if (var == 3) hipLaunchKernelGGL(probe<3>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, 15u);
-    if (var >= 4) hipLaunchKernelGGL(probe<7>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, 1u << (var - 3));
+    if (var >= 4 && var < 9) hipLaunchKernelGGL(probe<7>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, 1u << (var - 3));
+    if (var >= 9) hipLaunchKernelGGL(probe<9>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, g_quiet[var - 9]);
     tag0 += passes;
   };
-  for (int var = 0; var < max_var; ++var) {
+  for (int var = min_var; var < max_var; ++var) {
     printf("variant %d (%s)\n", var, var == 0 ? "agent scope on both levels" : var == 1 ? "level 1 through the XCD's L2 (sc0)" :
            var == 2 ? "level 1 through the L2, leaders all-to-all at agent scope, total handed back through the L2" :
            var == 3 ? "agent scope, four waves poll out of phase (150 ns apart)" :
-           "agent scope, the group sums replicated 2 / 4 / 8 / 16 / 32 times (variants 4 .. 8), 4 KB apart; a workgroup polls replica blockIdx % R");
+           var < 9 ? "agent scope, the group sums replicated 2 / 4 / 8 / 16 / 32 times (variants 4 .. 8), 4 KB apart; a workgroup polls replica blockIdx % R" :
+           "agent scope; no level-2 poll before it can succeed: members / leaders stay quiet 1.0/0, 1.4/0, 1.7/0, 2.0/0, 1.4/0.3, 1.7/0.3, 1.7/0.5, 2.0/0.5 us (variants 9 .. 16)");
     for (unsigned work_ns : {0u, 1000u, 2000u}) {
       for (int passes : {9, 900}) {
         launch(var, passes, work_ns / 10u);  // warm-up
@@ -243,6 +275,18 @@ int main(int argc, char **argv) {
         for (int i = 0; i < grid; ++i) differ += h[grid + i] != h[grid];  // every workgroup must have seen the same total
         u64 mism = 0;
         CK(hipMemcpy(&mism, &xb->xcc_mismatch, sizeof mism, hipMemcpyDeviceToHost));
+#ifdef POLLSTATS
+        {
+          unsigned long long hp[2][2], ht[2][2], z[2][2] = {{0, 0}, {0, 0}};
+          CK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_polls), sizeof hp));
+          CK(hipMemcpyFromSymbol(ht, HIP_SYMBOL(g_ticks), sizeof ht));
+          CK(hipMemcpyToSymbol(HIP_SYMBOL(g_polls), z, sizeof z));
+          CK(hipMemcpyToSymbol(HIP_SYMBOL(g_ticks), z, sizeof z));
+          const double ex = (double)passes * (reps + 1);
+          printf("    per exchange: leader level 1: %.2f polls, %.2f us; leader level 2: %.2f polls, %.2f us; member level 2: %.2f polls, %.2f us\n",
+                 hp[0][0] / ex, ht[0][0] * 0.01 / ex, hp[0][1] / ex, ht[0][1] * 0.01 / ex, hp[1][1] / ex, ht[1][1] * 0.01 / ex);
+        }
+#endif
         printf("  work %4u ns, %3d passes per launch: %.2f us per launch, %.2f us per pass (exchange + work), aborted workgroups %d, "
                "workgroups with a different total %d, XCC_ID != blockIdx %% 8 so far: %llu\n", work_ns, passes, ms / reps * 1e3,
                ms / reps * 1e3 / passes, bad, differ, mism);
