@@ -58,10 +58,18 @@ def main():
     if os.environ.get("TS_EXPECT_KPS"):       # which kernel sequence the test means to exercise
         assert kps == int(os.environ["TS_EXPECT_KPS"]), f"kernels per SNP: {kps}"
     locs = np.random.default_rng(seed + 3).integers(0, l, size=nsnp).astype(np.uint32)
+    switch = os.environ.get("TS_SWITCH_MODES") == "1"   # ts_schedule -> one launch per pass -> ts_schedule, mid-run
     eng.run_schedule(locs[:5])          # eager path
     eng.synchronize()
+    if switch:
+        eng.set_launch_mode(ts.LAUNCH_PER_PASS)
     its = [eng.snp_update(int(locs[5]))]
-    eng.run_schedule(locs[6:])          # graph replay path when long enough
+    if switch:
+        eng.run_schedule(locs[6:20])
+        eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+        eng.run_schedule(locs[20:])
+    else:
+        eng.run_schedule(locs[6:])      # graph replay path when long enough
     eng.synchronize()
     full = tdist.gather_rows(eng.get_gamma(), n, d, ts.shard_range)
     cnt = tdist.gather_rows(eng.get_counts().astype(np.float64)[:, None], n, d, ts.shard_range)

@@ -151,6 +151,17 @@ def test_sharded_schedule_kernel_matches_oracle(tmp_path, world, n, k, thresh, m
         assert np.array_equal(res[0]["cnt"], ref[0]["cnt"])
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ranks_switch_launch_modes_mid_run(tmp_path, world):
+    """ts_schedule (in-launch exchange across the ranks) -> one launch per pass (epoch-tagged peer-to-peer rows with the
+    progress guard) -> ts_schedule again on the same contexts: the State and the epoch one sequence leaves are the other's
+    start on every rank."""
+    n, l, k, seed, nsnp = 50_000, 24, 6, 19, 44
+    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp, extra_env={"TS_SWITCH_MODES": "1", "TS_EXPECT_KPS": "0"})
+    orc, its = _oracle_run(n, l, k, seed, nsnp)
+    _assert_ranks_match(res, orc, its)
+
+
 def test_rccl_two_ranks_matches_oracle(tmp_path):
     """The RCCL all-reduce exchange with more than one rank.  On a box with fewer GPUs than ranks
     RCCL refuses the communicator (two ranks on one device): skipped there, with RCCL's message."""
