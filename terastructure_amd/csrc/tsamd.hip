@@ -696,8 +696,10 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   c->sched_cap = 1024;
   CREATE_TRY(hipMalloc((void **)&c->d_sched, c->sched_cap * sizeof(uint32_t)));
 
-  CREATE_TRY(hipHostMalloc((void **)&c->h_error, 2 * sizeof(unsigned long long), hipHostMallocDefault));
-  c->h_error[0] = c->h_error[1] = 0ull;  // [0] error tag, [1] inner passes of the last completed SNP (DevParams::host_error)
+  // pinned words the kernels write (DevParams::host_error): [0] error tag, [1] inner passes of the last completed SNP,
+  // [2] total passes, [3 + b] pass histogram
+  CREATE_TRY(hipHostMalloc((void **)&c->h_error, (3 + TSAMD_PASS_HIST_BINS) * sizeof(unsigned long long), hipHostMallocDefault));
+  memset(c->h_error, 0, (3 + TSAMD_PASS_HIST_BINS) * sizeof(unsigned long long));
   p.host_error = c->h_error;
   if (c->resident) {
     CREATE_TRY(hipMalloc((void **)&c->res, sizeof(ResXchg)));
@@ -1258,9 +1260,7 @@ int tsamd_total_passes(tsamd_ctx *c, uint64_t *passes) {
   if (!passes) return fail(c, TSAMD_EINVAL, "null output");
   HIP_TRY(c, hipSetDevice(c->dev));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  unsigned long long v = 0;
-  HIP_TRY(c, hipMemcpy(&v, &c->p.ctl->total_passes, sizeof v, hipMemcpyDeviceToHost));
-  *passes = v;
+  *passes = *(volatile unsigned long long *)(c->h_error + 2);  // (mirrored by the kernel that publishes a SNP: no copy)
   return TSAMD_OK;
 }
 
@@ -1270,7 +1270,7 @@ int tsamd_pass_histogram(tsamd_ctx *c, uint64_t hist[TSAMD_PASS_HIST_BINS]) {
   HIP_TRY(c, hipSetDevice(c->dev));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "histogram element size");
-  HIP_TRY(c, hipMemcpy(hist, c->p.ctl->pass_hist, sizeof(uint64_t) * TSAMD_PASS_HIST_BINS, hipMemcpyDeviceToHost));
+  for (int b = 0; b < TSAMD_PASS_HIST_BINS; ++b) hist[b] = *(volatile unsigned long long *)(c->h_error + 3 + b);
   return TSAMD_OK;
 }
 

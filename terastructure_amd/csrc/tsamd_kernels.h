@@ -136,6 +136,21 @@ __device__ __forceinline__ bool finish_pending(const DevParams &p, const Pending
   return epilogue_complete(p, in.iters, J, s_diff);
 }
 
+// The SNP counters of Ctl, mirrored into the pinned host words (DevParams::host_error: [1] inner passes of the last
+// completed SNP, [2] total passes, [3 + b] pass histogram bin b) by the one thread that publishes a SNP: the host reads
+// them after a stream synchronise without a device-to-host copy (tsamd_snp_update, tsamd_total_passes, tsamd_pass_histogram).
+__device__ __forceinline__ void count_snp(const DevParams &p, Ctl *ctl, uint32_t iters) {
+  const uint32_t bin = min(iters, (uint32_t)TSAMD_PASS_HIST_BINS - 1u);
+  ctl->last_iters = iters;
+  ctl->total_passes += (unsigned long long)iters;
+  ctl->pass_hist[bin] += 1ull;
+  if (p.host_error) {
+    __hip_atomic_store(p.host_error + 1, (unsigned long long)iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p.host_error + 2, ctl->total_passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p.host_error + 3 + bin, ctl->pass_hist[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // workgroup 0 publishes the completed SNP: final lambda / exp(Elogbeta) into the global
 // arrays, counters, and the carried-forward state (eb stays the one the LAST executed
 // pass used: the deferred gamma step needs it, src/snpsamplinge.cc:660-668).
@@ -152,10 +167,7 @@ __device__ __forceinline__ void publish_complete(const DevParams &p, Ctl *ctl, c
     }
   }
   if (tid == 0) {
-    ctl->last_iters = S->iters;
-    if (p.host_error) __hip_atomic_store(p.host_error + 1, (unsigned long long)S->iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    ctl->total_passes += (unsigned long long)S->iters;
-    ctl->pass_hist[min(S->iters, (uint32_t)TSAMD_PASS_HIST_BINS - 1u)] += 1ull;
+    count_snp(p, ctl, S->iters);
     if (write_state) {
       W->idx = S->idx;
       W->valid = 1u;
@@ -181,10 +193,7 @@ __device__ __forceinline__ void publish_complete_v(const DevParams &p, Ctl *ctl,
     W->eb[tid] = eb_last;  // exp(Elogbeta) the LAST executed pass used (the deferred gamma step needs it)
   }
   if (tid == 0) {
-    ctl->last_iters = iters;
-    if (p.host_error) __hip_atomic_store(p.host_error + 1, (unsigned long long)iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    ctl->total_passes += (unsigned long long)iters;
-    ctl->pass_hist[min(iters, (uint32_t)TSAMD_PASS_HIST_BINS - 1u)] += 1ull;
+    count_snp(p, ctl, iters);
     W->idx = idx;
     W->valid = 1u;
     W->loc = loc;
@@ -1617,10 +1626,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         __hip_atomic_store(&p.eb[(size_t)loc * J + tid], s_eb[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (tid == 0) {
-        ctl->last_iters = iters;
-        if (p.host_error) __hip_atomic_store(p.host_error + 1, (unsigned long long)iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        ctl->total_passes += (unsigned long long)iters;
-        ctl->pass_hist[min(iters, (uint32_t)TSAMD_PASS_HIST_BINS - 1u)] += 1ull;
+        count_snp(p, ctl, iters);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // published before this workgroup joins the next exchange
     }
