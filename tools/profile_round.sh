@@ -11,12 +11,12 @@ grep '^{' gpurun_out/prof_persnp/bench.log > $O/k8_per_snp_bench_under_rocprof.j
 bash tools/prof.sh k20 -- --pops 20 --snps 200000 --steps 300 --warmup 50 --cpu-seconds 0 > $O/k20_kernel_trace.txt 2>&1
 grep '^{' gpurun_out/prof_k20/bench.log > $O/k20_bench_under_rocprof.json
 # counters: the largest launch of a run is the 200-update ts_schedule launch (per update = max / 200)
-A="--steps 200 --warmup 10 --cpu-seconds 0 --no-profile --l 20000"
+A="--steps 200 --warmup 10 --ramp-seconds 0 --cpu-seconds 0 --no-profile --l 20000"
 bash tools/pmc.sh fetch FETCH_SIZE -- $A > $O/k8_pmc_fetch_size.txt 2>&1
 bash tools/pmc.sh write WRITE_SIZE -- $A > $O/k8_pmc_write_size.txt 2>&1
 bash tools/pmc.sh sq1 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY" -- $A > $O/k8_pmc_sq1.txt 2>&1
 bash tools/pmc.sh sq2 "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQC_ICACHE_REQ SQC_ICACHE_MISSES" -- $A > $O/k8_pmc_sq2.txt 2>&1
-B="--steps 60 --warmup 10 --cpu-seconds 0 --no-profile --l 20000"
+B="--steps 60 --warmup 10 --ramp-seconds 0 --cpu-seconds 0 --no-profile --l 20000"
 TSAMD_PERSISTENT=0 bash tools/pmc.sh fetchps FETCH_SIZE -- $B > $O/k8_per_snp_pmc_fetch_size.txt 2>&1
 TSAMD_PERSISTENT=0 bash tools/pmc.sh writeps WRITE_SIZE -- $B > $O/k8_per_snp_pmc_write_size.txt 2>&1
 bash tools/pmc.sh fetch20 FETCH_SIZE -- $B --pops 20 > $O/k20_pmc_fetch_size.txt 2>&1
