@@ -26,6 +26,7 @@ struct Xb {
   u64 bc[2][kGroups][kGran];            // variant 2: the total, handed back inside the XCD
   u64 rep[2][32][512];                  // variants 7+: replicas of sums (4 KB apart: 2 KB of granules + padding), so that the
                                         // 256 pollers do not all read the same 2 KB through one memory channel
+  u64 flat[2][kGroups * kPerGroup][kGran];  // variant 25: one level -- every workgroup polls every workgroup's row
   u64 abort_word;
   u64 xcc_mismatch;                     // workgroups whose XCC_ID is not blockIdx % 8
 };
@@ -146,6 +147,34 @@ __global__ __launch_bounds__(512) void probe(Xb *xb, int passes, unsigned tag0, 
       const u64 t0 = wall_clock64();
       while (wall_clock64() - t0 < work_ticks) __builtin_amdgcn_s_sleep(2);
     }
+    if constexpr (VAR == 25) {
+      // ONE level: every workgroup stores its row, waits `stagger_ticks` (the expected skew), and its waves 0..3 each
+      // poll 64 of the 256 rows (32 loads per lane); partial sums through LDS, added in wave order
+      __shared__ double s_part[4][kJ];
+      if (tid < kJ) {
+        const u64 bits = __double_as_longlong(acc * (double)(tid + 1));
+        put(&xb->flat[p & 1][blockIdx.x][2 * tid], tag, (unsigned)bits);
+        put(&xb->flat[p & 1][blockIdx.x][2 * tid + 1], tag, (unsigned)(bits >> 32));
+      }
+      if (wave < 4) {
+        unsigned v[32];
+        alive = sweep<32>(&xb->flat[p & 1][64 * wave][0], tag, v, &xb->abort_word, nullptr, stagger_ticks) != 0;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const unsigned other = __shfl_xor((int)v[i], 1);
+          s += (lane & 1u) ? join(other, v[i]) : join(v[i], other);
+        }
+        s += __shfl_xor(s, 32);
+        if (lane < 32u && !(lane & 1u)) s_part[wave][lane >> 1] = s;
+      }
+      __syncthreads();
+      if (tid < kJ) s_tot[tid] = ((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid];
+      __syncthreads();
+      alive = __syncthreads_and(alive ? 1 : 0) != 0;
+      acc = acc * 0.5 + s_tot[0] * 1e-6;
+      continue;
+    }
     // the workgroup's row: value j = acc * (j + 1)  (thread j < 16 owns value j)
     if (tid < kJ) {
       const u64 bits = __double_as_longlong(acc * (double)(tid + 1));
@@ -248,7 +277,8 @@ int main(int argc, char **argv) {
     if (var == 2) hipLaunchKernelGGL(probe<2>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, 0u);
     if (var == 3) hipLaunchKernelGGL(probe<3>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, 15u);
     if (var >= 4 && var < 9) hipLaunchKernelGGL(probe<7>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, 1u << (var - 3));
-    if (var >= 9) hipLaunchKernelGGL(probe<9>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, g_quiet[var - 9]);
+    if (var >= 9 && var < 17) hipLaunchKernelGGL(probe<9>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, g_quiet[var - 9]);
+    if (var >= 17) hipLaunchKernelGGL(probe<25>, dim3(grid), dim3(512), 0, 0, xb, passes, tag0, ticks, out, (unsigned)(var - 17) * 20u);
     tag0 += passes;
   };
   for (int var = min_var; var < max_var; ++var) {
@@ -256,7 +286,8 @@ int main(int argc, char **argv) {
            var == 2 ? "level 1 through the L2, leaders all-to-all at agent scope, total handed back through the L2" :
            var == 3 ? "agent scope, four waves poll out of phase (150 ns apart)" :
            var < 9 ? "agent scope, the group sums replicated 2 / 4 / 8 / 16 / 32 times (variants 4 .. 8), 4 KB apart; a workgroup polls replica blockIdx % R" :
-           "agent scope; no level-2 poll before it can succeed: members / leaders stay quiet 1.0/0, 1.4/0, 1.7/0, 2.0/0, 1.4/0.3, 1.7/0.3, 1.7/0.5, 2.0/0.5 us (variants 9 .. 16)");
+           var < 17 ? "agent scope; no level-2 poll before it can succeed: members / leaders stay quiet 1.0/0, 1.4/0, 1.7/0, 2.0/0, 1.4/0.3, 1.7/0.3, 1.7/0.5, 2.0/0.5 us (variants 9 .. 16)" :
+           "ONE level: every workgroup polls all 256 rows (64 KB) with four waves, first poll 0 / 0.2 / 0.4 / 0.6 / 0.8 us after its own store (variants 17 .. 21)");
     for (unsigned work_ns : {0u, 1000u, 2000u}) {
       for (int passes : {9, 900}) {
         launch(var, passes, work_ns / 10u);  // warm-up
