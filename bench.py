@@ -34,7 +34,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import rel_err, usable_cores  # noqa: E402  (tests/helpers.py: numpy only)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (half the 157.3 TFLOP/s fp32 vector rate of MI355X_MICROARCH.md)
 SELFTEST_TOL = 1e-9    # exchange self-test: lambda / gamma vs the CPU oracle after 6 updates (rel)
+
+
+def resident_geometry(k):
+    """(individuals per item, items per thread, items whose gamma stays in LDS) of the resident kernels --
+    mirrors resident_vec / resident_items / sched_lds_items in csrc/tsamd_resident_kernels.h"""
+    vec = 2 if k <= 8 else 1
+    items = 8 if k <= 8 else 128 // k if k <= 16 else 112 // k if k <= 24 else 3
+    small = 1024 + 18 * 2 * k * 8
+    lds = min(items, (160 * 1024 - small) // ((k * 8 + 4) * vec * 256))
+    return vec, items, lds
 
 
 def parse():
@@ -164,6 +175,10 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
                 tt = torch.tensor([dt], dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 report["updates_per_s"][mode] = round((len(locs) - 60) / float(tt.item()), 1)
+                # (to read the first real multi-GPU run against the single-GPU figures: DESIGN.md section 5 predicts the
+                # per-pass cost of each candidate; one GPU: 6.2 us per pass inside ts_schedule, 2.9 of them in the exchange)
+                report.setdefault("us_per_update", {})[mode] = round(float(tt.item()) / (len(locs) - 60) * 1e6, 2)
+                report.setdefault("us_per_pass", {})[mode] = round(float(tt.item()) / (len(locs) - 60) * 1e6 / 10.0, 2)
                 if e6 < SELFTEST_TOL:
                     final[mode] = res
                     report["valid"][mode] = True
@@ -421,34 +436,40 @@ def main():
             launches = pr["first_launches"] if resident else pr["pass_launches"]
             avg_s = pr["pass_ms"] / launches * 1e-3
             alg_bytes = passes_per_launch * pass_bytes
-            achieved = alg_bytes / avg_s / 1e9
+            equiv = None
             if resident:
-                kernel = (f"ts_resident<K> (all {passes_per_launch:.3g} plain passes of a SNP in one launch: weights read once, "
+                # the resident kernel reads the weights from memory ONCE per SNP and runs the later passes from registers:
+                # its memory roofline is what it must move (weights once, one column), not passes x the plain-pass bytes
+                equiv = {"bytes_per_launch": alg_bytes, "GBps": round(alg_bytes / avg_s / 1e9, 1),
+                         "note": "passes x (8NK + N/4), the reference's dataflow, over this kernel's time: not a fraction of any peak"}
+                alg_bytes = pass_bytes
+                kernel = (f"ts_resident<{k}> (all {passes_per_launch:.3g} plain passes of a SNP in one launch: weights read once, "
                           "kept in registers; partial rows exchanged inside the launch)")
-                note = ("algorithmic bytes = passes x (8NK + N/4): what the reference's dataflow moves.  The resident kernel reads "
-                        "the weights from memory ONCE per SNP (see traffic) and runs the later passes from registers, so its "
-                        "algorithmic bandwidth can exceed the 8 TB/s HBM peak (frac > 1): the bound that remains is the in-launch "
-                        "exchange (about 3 us per pass) plus the epilogue, not memory.  probe_read_us is a bare streaming read of "
-                        "the weights on this box (tsamd_probe_stream); per_pass_us x passes = avg_launch_us.")
+                note = ("achieved = the bytes the kernel must move per launch (the N x K weights once + one 2-bit column) over its "
+                        "launch time; `traffic` is the counter figure.  It is bound by neither memory nor arithmetic but by the "
+                        "in-launch exchange (about 3 us per pass with the ALU idle) plus the fp64 sweeps (2.6 us per pass at N = 1M, "
+                        "K = 8): per_pass_us x passes = avg_launch_us.  probe_read_us is a bare streaming read of the weights on this "
+                        "box (tsamd_probe_stream).")
             else:
-                kernel = "ts_pass<K,false> (plain pass, max_inner - 1 launches per update)"
+                kernel = f"ts_pass<{k},false> (plain pass, max_inner - 1 launches per update)"
                 note = ("fabric-side bandwidth incl. Infinity Cache, not DRAM bandwidth: the pass re-reads the same weights (8NK "
                         "bytes: 64 MB at N=1M, K=8) every launch and they stay in the 256 MiB Infinity Cache; FETCH_SIZE counts "
                         "those hits.  probe_read_us is a bare streaming read of the same array with the same geometry on this "
                         "box (tsamd_probe_stream): the second denominator.")
+            achieved = alg_bytes / avg_s / 1e9
             per_snp = {
                 "bound": "hbm", "kernel": kernel,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("hbm_bytes_per_launch"),
-                "algorithmic_bytes_per_launch": alg_bytes,
+                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bandwidth_equiv": equiv,
                 "avg_launch_us": round(avg_s * 1e6, 3), "launches_timed": launches,
                 "passes_per_launch": round(passes_per_launch, 3),
                 "per_pass_us": round(avg_s * 1e6 / passes_per_launch, 3),
                 "ceiling_note": note,
                 "probe_read_us": None if read_us is None else round(read_us, 3),
-                "frac_of_probe": None if read_us is None else round(read_us * 1e-6 * passes_per_launch / avg_s, 4),
+                "frac_of_probe": None if read_us is None else round(read_us * 1e-6 / avg_s, 4),
                 "first_pass": {
-                    "kernel": "ts_pass<K,true> (first pass of a SNP + the previous SNP's gamma step, 1 launch per update)",
+                    "kernel": f"ts_pass<{k},true> (first pass of a SNP + the previous SNP's gamma step, 1 launch per update)",
                     "bound": "hbm", "achieved": round(first_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(first_achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("first_pass_hbm_bytes_per_launch"),
                     "algorithmic_bytes_per_launch": first_bytes, "avg_launch_us": round(first_s * 1e6, 3),
@@ -458,55 +479,74 @@ def main():
                 },
             }
         if mode == "schedule":
-            # the dominant (only) kernel of the timed region: ONE launch runs the whole schedule.  Algorithmic bytes per
-            # launch = what the reference's dataflow moves for the updates of that launch: per update one first pass
-            # (32NK + 8N + N/2: weights and gamma read and written, c_n, two columns) + (passes - 1) plain passes (8NK + N/4).
+            # the dominant (only) kernel of the timed region: ONE launch runs the whole schedule.
             nsteps = min(args.steps, 2000)
             prs, ran = profiled(nsteps)
             if prs["pass_launches"]:
                 rec = pmc_record("schedule")
                 launch_s = prs["pass_ms"] / prs["pass_launches"] * 1e-3
                 upd = nsteps / prs["pass_launches"]
-                alg_bytes = (nsteps * first_bytes + max(0, ran - nsteps) * pass_bytes) / prs["pass_launches"]
-                achieved = alg_bytes / launch_s / 1e9
-                # what ts_schedule itself must move per update: gamma and c_n, read and written, of the items whose gamma
-                # is not kept in LDS (csrc/tsamd_kernels.h: sched_lds_items -- half of them at K = 8, none at K <= 4), a column
-                n_lds = min(8, (160 * 1024 - 4096) // ((k * 16 + 8) * 256))
-                moved = (16.0 * sc * k + 8.0 * sc) * (8 - n_lds) / 8.0 + sc / 4.0
+                ppu = ran / nsteps                                   # passes per update
+                # (1) what binds it: fp64 vector arithmetic at one wave per SIMD.  Flops per update from the SQ counters of
+                # a profiled launch when a record for this (N, K) is committed (profiles/pass_kernel_pmc.json, built from
+                # rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64), else the hand count of the kernel's own
+                # formulation (FMA = 2): a sweep is 8K + 20 per individual (two K-term normalisers, two reciprocals, 2K
+                # accumulations per parent), the gamma step 124K + 30 (normalisers 4K, update 12K, exp(psi) 108K).
+                hand = ppu * sc * (8.0 * k + 20.0) + sc * (124.0 * k + 30.0)
+                flops = rec.get("fp64_flops_per_update")
+                flops_src = "hand count of the kernel's formulation (no counter record for this N, K in profiles/pass_kernel_pmc.json)"
+                if flops:
+                    flops_src = "SQ_INSTS_VALU_*_F64 counters of a profiled launch: " + ", ".join(rec.get("flops_source_files", []))
+                else:
+                    flops = hand
+                tflops = flops * upd / launch_s / 1e12
+                # (2) memory: what the kernel itself must move per update -- gamma and c_n, read and written, of the items
+                # whose gamma is not kept in LDS, one 2-bit column -- and what the counters saw
+                vec, items, n_lds = resident_geometry(k)
+                moved = (16.0 * sc * k + 8.0 * sc) * (items - n_lds) / items + sc / 4.0
                 traffic = rec.get("hbm_bytes_per_update")
+                # (3) the reference's dataflow: per update one first pass 32NK + 8N + N/2 and passes - 1 plain
+                # passes 8NK + N/4 -- what this kernel would have to move if the weights did not stay in registers
+                alg_bytes = (nsteps * first_bytes + max(0, ran - nsteps) * pass_bytes) / prs["pass_launches"]
+                # (4) latency: the in-launch exchanges, during which the vector ALU idles (in-kernel timers of the
+                # diagnostic build -DTSAMD_SCHED_TIME, recorded with the counters)
+                xus = rec.get("exchange_us_per_update")
                 roofline = {
-                    "bound": "hbm",
-                    "kernel": (f"ts_schedule<K> (one launch = {upd:.0f} SNP updates: the gamma step and all {ran / nsteps:.3g} passes of every "
+                    "bound": "fp64_valu",
+                    "kernel": (f"ts_schedule<{k}> (one launch = {upd:.0f} SNP updates: the gamma step and all {ppu:.3g} passes of every "
                                "SNP; weights in registers from the first SNP to the last; partial rows exchanged inside the launch)"),
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "achieved": round(tflops, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4),
                     "traffic": None if traffic is None else traffic * upd,
-                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(launch_s * 1e6, 1),
-                    "launches_timed": prs["pass_launches"], "updates_per_launch": upd,
-                    "per_update_us": round(launch_s * 1e6 / upd, 3), "passes_per_update": round(ran / nsteps, 3),
-                    "algorithmic_bytes_per_update": alg_bytes / upd,
-                    "moved_bytes_per_update": moved,
-                    "moved_floor_us_per_update": round(moved / (HBM_PEAK_GBS * 1e9) * 1e6, 3),
-                    "moved_GBps": round(moved * upd / launch_s / 1e9, 1),   # what the kernel really asks of memory ...
-                    "moved_frac": round(moved * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),  # ... as a fraction of the HBM peak
-                    "ceiling_note": ("algorithmic bytes = the reference's dataflow (every pass re-reads the N x K weights, the gamma step "
-                                     "reads and writes weights and gamma).  ts_schedule keeps the weights in registers, so per update it "
-                                     "moves only moved_bytes_per_update (gamma read + write, c_n, one 2-bit column; `traffic` is the "
-                                     "counter-measured figure) and frac -- algorithmic bandwidth over the 8 TB/s HBM peak -- can exceed 1.  "
-                                     "What bounds the kernel instead (in-kernel timers of the diagnostic build, profiles/r02_experiments.md): "
-                                     "the gamma step's fp64 arithmetic (digamma + exp per individual and population, one wave per SIMD) and "
-                                     "the in-launch exchange of the partial rows (two dependent memory round trips per pass).  "
-                                     "launch_per_snp holds the kernels of the launch-per-SNP sequence on the same data (the default "
-                                     "mode for K > 8, sharded runs and larger shards), measured right after."),
-                    # the other roofline: fp64 vector arithmetic (no MFMA on this path).  Flops of the kernel's own formulation,
-                    # FMA = 2: a sweep is 8K + 20 per individual (two K-term normalisers, two reciprocals, 2K accumulations per
-                    # parent), the gamma step 124K + 30 (normalisers 4K, update 12K, exp(psi) 108K per individual)
-                    "fp64_valu": {
-                        "flops_per_update": (ran / nsteps) * sc * (8.0 * k + 20.0) + sc * (124.0 * k + 30.0),
-                        "achieved_TFLOPs": round(((ran / nsteps) * sc * (8.0 * k + 20.0) + sc * (124.0 * k + 30.0)) * upd / launch_s / 1e12, 2),
-                        "peak_TFLOPs": 78.6,
-                        "frac": round(((ran / nsteps) * sc * (8.0 * k + 20.0) + sc * (124.0 * k + 30.0)) * upd / launch_s / 1e12 / 78.6, 4),
-                        "note": ("MI355X fp64 vector peak 78.6 TFLOP/s (half the 157.3 TFLOP/s fp32 vector rate of MI355X_MICROARCH.md); "
-                                 "tools/fma_probe reaches 62.5 TFLOP/s with one wave per SIMD, the occupancy this kernel runs at"),
+                    "flops_per_update": flops, "flops_per_update_hand_count": hand, "flops_source": flops_src,
+                    "avg_launch_us": round(launch_s * 1e6, 1), "launches_timed": prs["pass_launches"], "updates_per_launch": upd,
+                    "per_update_us": round(launch_s * 1e6 / upd, 3), "passes_per_update": round(ppu, 3),
+                    "bound_note": ("fp64 vector issue: the kernel runs one wave per SIMD (a thread owns the whole register file), where "
+                                   "tools/fma_probe reaches 62.5 of the 78.6 TFLOP/s; the rest of the distance is the exchange latency "
+                                   "(`latency`) and instructions that are not flops (register moves between the AGPR-resident weights "
+                                   "and the ALU, reciprocal refinements, code decode).  HBM is far from binding (`hbm`)."),
+                    "hbm": {
+                        "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "achieved": None if traffic is None else round(traffic * upd / launch_s / 1e9, 1),
+                        "frac": None if traffic is None else round(traffic * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                        "traffic_bytes_per_update": traffic,
+                        "moved_bytes_per_update": moved, "moved_GBps": round(moved * upd / launch_s / 1e9, 1),
+                        "moved_frac": round(moved * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": ("achieved / frac: FETCH_SIZE x 2 + WRITE_SIZE of a profiled launch (profiles/pass_kernel_pmc.json) over "
+                                 "this run's launch time; moved_*: the bytes the kernel must move by construction (streamed gamma "
+                                 "read + write, c_n, one 2-bit column)"),
+                    },
+                    "algorithmic_bandwidth_equiv": {
+                        "bytes_per_update": alg_bytes / upd, "GBps": round(alg_bytes / launch_s / 1e9, 1),
+                        "note": ("SURVEY 8(d) bytes of the reference's dataflow (every pass re-reads the N x K weights) over this kernel's "
+                                 "time: a speed-up figure against a memory-bound implementation, not a fraction of any peak -- the "
+                                 "kernel does not move these bytes"),
+                    },
+                    "latency": {
+                        "exchanges_per_update": round(ppu, 3),
+                        "exchange_us_per_update": xus,
+                        "frac_of_update": None if xus is None else round(xus / (launch_s * 1e6 / upd), 4),
+                        "source": rec.get("exchange_source", "no in-kernel timer record for this N, K"),
                     },
                     "launch_per_snp": per_snp,
                     "first_pass": None if per_snp is None else per_snp["first_pass"],
@@ -575,20 +615,40 @@ def main():
                          f"{cores} usable under its affinity mask / cgroup quota); value_1_thread: "
                          f"{done1} updates with one thread"}
         # the same updates on the GPU, from the same state (lambda of the sample columns back to
-        # eta, gamma and c_n back to the start, no pending step), through the timed entry point
+        # eta, gamma and c_n back to the start, no pending step), through the timed entry point -- in the mode that was
+        # timed and in every other launch mode whose kernels this line publishes timings of (roofline.launch_per_snp /
+        # first_pass)
         eta = np.ones((k, 2))
-        for j in range(ls):
-            eng.set_lambda(j, eta)
-        eng.set_gamma(g0)
-        eng.set_counts(np.zeros(n, dtype=np.uint32))
-        eng.clear_pending()
-        eng.run_schedule(np.array(seq, dtype=np.uint32))
-        eng.synchronize()
-        e_lam = rel_err(eng.get_lambda(0, ls), want[0])
-        e_gam = rel_err(eng.get_gamma(), want[1])
-        cnt_eq = bool(np.array_equal(eng.get_counts(), want[2]))
-        parity = {"lambda_rel_err": e_lam, "gamma_rel_err": e_gam, "c_n_equal": cnt_eq, "updates": len(seq),
-                  "tolerance": 1e-9, "ok": bool(e_lam < 1e-9 and e_gam < 1e-9 and cnt_eq)}
+
+        def gpu_repeat():
+            for j in range(ls):
+                eng.set_lambda(j, eta)
+            eng.set_gamma(g0)
+            eng.set_counts(np.zeros(n, dtype=np.uint32))
+            eng.clear_pending()
+            eng.run_schedule(np.array(seq, dtype=np.uint32))
+            eng.synchronize()
+            e_lam = rel_err(eng.get_lambda(0, ls), want[0])
+            e_gam = rel_err(eng.get_gamma(), want[1])
+            cnt_eq = bool(np.array_equal(eng.get_counts(), want[2]))
+            return {"lambda_rel_err": e_lam, "gamma_rel_err": e_gam, "c_n_equal": cnt_eq,
+                    "ok": bool(e_lam < 1e-9 and e_gam < 1e-9 and cnt_eq)}
+
+        parity = gpu_repeat()
+        parity.update({"updates": len(seq), "tolerance": 1e-9, "kernels_per_snp": eng.launch_info()["kernels_per_snp"]})
+        timed_kps = eng.launch_info()["kernels_per_snp"]
+        others = {}
+        for name, m in (("launch_per_snp", ts.LAUNCH_PER_SNP), ("launch_per_pass", ts.LAUNCH_PER_PASS)):
+            try:
+                eng.set_launch_mode(m)
+            except ts.TsamdError:
+                continue                                  # the context does not qualify for it
+            if eng.launch_info()["kernels_per_snp"] != timed_kps:
+                others[name] = gpu_repeat()
+                others[name]["kernels_per_snp"] = eng.launch_info()["kernels_per_snp"]
+        if others:
+            parity["other_launch_modes"] = others
+            parity["ok"] = bool(parity["ok"] and all(o["ok"] for o in others.values()))
 
     if rank == 0:
         alg_update = (mean_passes + 4) * 8.0 * n * k + (mean_passes + 1) * n / 4.0 + 8.0 * n
@@ -606,8 +666,7 @@ def main():
             "mean_inner_passes": round(mean_passes, 3),
             "inner_passes_histogram": {str(i): int(c) for i, c in enumerate(hist) if c},
             "nk_pass_per_s": round(value * mean_passes * n * k, 1),
-            "update_algorithmic_bytes": alg_update,
-            "update_hbm_frac_of_peak": round(alg_update * value / (world * HBM_PEAK_GBS * 1e9), 4),
+            "update_algorithmic_bytes": alg_update,   # (what the reference's dataflow moves per update)
             "setup_s": round(setup_s, 1),
             "setup": {"clock_ramp_updates": ramp_n,
                       "note": ("untimed priming schedule queued right ahead of the warm-up, no synchronisation in between: the "

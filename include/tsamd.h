@@ -64,6 +64,7 @@ typedef struct tsamd_config {
 
 #define TSAMD_FLAG_SPLIT_EPILOGUE 1u /* run the sharded kernel sequence (pass, row sum, exchange) even on one GPU */
 #define TSAMD_FLAG_NO_GRAPH 2u       /* tsamd_run_schedule launches eagerly instead of replaying a hipGraph */
+#define TSAMD_FLAG_TEST_HOOKS 4u     /* honour the TSAMD_TEST_* environment hooks of the peer-to-peer exchange (tests only) */
 
 int tsamd_abi_version(void);
 void tsamd_default_config(tsamd_config *cfg, uint32_t n, uint32_t l, uint32_t k);
@@ -240,23 +241,39 @@ int tsamd_profile_read(tsamd_ctx *ctx, uint64_t *pass_launches, double *pass_ms_
  * wide-K fallback (k > TSAMD_SPECIALIZED_K) is probed with the same two kernels. */
 int tsamd_probe_stream(tsamd_ctx *ctx, uint32_t reps, double *read_us, double *rmw_us);
 /* how the context runs a SNP: kernels per SNP of the state-machine sequence (max_inner with one launch per
- * pass; 2 when all plain passes of a SNP run as one resident launch: single GPU, k <= 8, shards up to ~1M
- * individuals, TSAMD_RESIDENT=0 disables; 0 when a whole schedule runs as ONE launch with the weights kept in
- * registers: the same conditions plus nodekappa == 0.5, TSAMD_PERSISTENT=0 disables), workgroups of the
- * plain-pass and first-pass kernels */
+ * pass; 2 when all plain passes of a SNP run as one resident launch; 0 when a whole schedule runs as ONE launch with
+ * the weights kept in registers), workgroups of the plain-pass and first-pass kernels.  The resident kernels need
+ * k <= 32 and a shard that fits the register file of the GPU's compute units: 256 workgroups x
+ *   k <= 8: 4096,  k = 9..16: 256 floor(128/k),  k = 17..24: 256 floor(112/k),  k = 25..32: 768   individuals
+ * (1 048 576 per GPU at k <= 8, 524 288 at k = 16, 327 680 at k = 20); the whole-schedule kernel also nodekappa == 0.5.
+ * TSAMD_RESIDENT=0 / TSAMD_PERSISTENT=0 in the environment disable them. */
 int tsamd_launch_info(tsamd_ctx *ctx, uint32_t *kernels_per_snp, uint32_t *plain_grid, uint32_t *first_grid);
 /* Selects how the context launches from now on: one kernel per pass, one resident kernel for the plain passes of
  * a SNP, or one kernel per schedule.  tsamd_create picks the highest mode the context qualifies for; this call
  * can lower it and raise it again (TSAMD_EUNSUPPORTED above what the context qualifies for).  A sharded context
- * (tsamd_p2p_connect / _connect_local) qualifies for TSAMD_LAUNCH_PER_SCHEDULE when k <= 8, nodekappa == 0.5,
- * world <= 8 and every rank's shard fills 8 ... 256 workgroups (the in-launch exchange then spans the ranks; ranks
+ * (tsamd_p2p_connect / _connect_local) qualifies for TSAMD_LAUNCH_PER_SCHEDULE when nodekappa == 0.5, world <= 8 and
+ * every rank's shard fits as above and fills at least 8 workgroups (the in-launch exchange then spans the ranks; ranks
  * that share a device: TSAMD_DEVICE_SHARE=<ranks> in the environment), never for TSAMD_LAUNCH_PER_SNP.  All modes give the
  * same results to rounding (the order in which the workgroups' partial rows are added differs), and each mode is
- * bitwise reproducible and independent of how a schedule is cut into calls.  Synchronises the stream. */
+ * bitwise reproducible and independent of how a schedule is cut into calls.  Synchronises the stream.
+ *
+ * The resident kernels exchange partial sums between their workgroups inside the launch and therefore need all of
+ * them on the device at once.  Every such launch checks that first, with an empty exchange (bounded by
+ * TSAMD_PROBE_MS, default 100 ms), before it modifies anything.  If something else holds compute units (another
+ * context or process on the same GPU) the launch gives up with the state intact, every later kernel of the context
+ * becomes a no-op, and the next synchronising call (tsamd_synchronize, a getter, ...) lowers the context to
+ * TSAMD_LAUNCH_PER_PASS, replays the affected schedules from the unchanged state and returns success with a warning
+ * in tsamd_last_error -- the results are those of an undisturbed run (to rounding, as between modes).  tsamd_recoveries
+ * counts these events.  (The reference's counterpart: a run is never lost to its environment -- SIGTERM saves the
+ * model, src/snpsamplinge.cc:454-457.)  Sharded contexts report TSAMD_ECOMM instead. */
 #define TSAMD_LAUNCH_PER_PASS 0
 #define TSAMD_LAUNCH_PER_SNP 1      /* first pass + ts_resident */
 #define TSAMD_LAUNCH_PER_SCHEDULE 2 /* ts_schedule */
 int tsamd_set_launch_mode(tsamd_ctx *ctx, int mode);
+int tsamd_recoveries(tsamd_ctx *ctx, uint32_t *count);
+/* test / diagnostic aid: occupies `workgroups` compute units of the context's device for `milliseconds` with a
+ * kernel on a second stream (returns once it runs) -- what another tenant of the GPU looks like to the resident kernels. */
+int tsamd_debug_occupy(tsamd_ctx *ctx, uint32_t workgroups, uint32_t milliseconds);
 /* device memory in bytes currently free / total on the context's device */
 int tsamd_mem_info(tsamd_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 

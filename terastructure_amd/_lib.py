@@ -11,6 +11,7 @@ COMM_ID_BYTES = 128
 P2P_HANDLE_BYTES = 64
 FLAG_SPLIT_EPILOGUE = 1
 FLAG_NO_GRAPH = 2
+FLAG_TEST_HOOKS = 4
 LAUNCH_PER_PASS, LAUNCH_PER_SNP, LAUNCH_PER_SCHEDULE = 0, 1, 2  # tsamd_set_launch_mode
 PASS_HIST_BINS = 128
 
@@ -80,6 +81,8 @@ SYMBOLS = {
     "tsamd_probe_stream": (_int, [_vp, _u32, _pd, _pd]),
     "tsamd_launch_info": (_int, [_vp, _pu32, _pu32, _pu32]),
     "tsamd_set_launch_mode": (_int, [_vp, _int]),
+    "tsamd_recoveries": (_int, [_vp, _pu32]),
+    "tsamd_debug_occupy": (_int, [_vp, _u32, _u32]),
     "tsamd_mem_info": (_int, [_vp, _pu64, _pu64]),
 }
 

@@ -1,7 +1,7 @@
 """Builds libtsamd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
 The K-specialised kernels are compiled as one translation unit per K
-(csrc/tsamd_inst.hip with -DTSAMD_K=k, plus csrc/tsamd_sched.hip for K <= 8), in parallel; objects are cached under
+(csrc/tsamd_inst.hip and csrc/tsamd_sched.hip with -DTSAMD_K=k), in parallel; objects are cached under
 terastructure_amd/lib/obj and rebuilt when a source they include changes.
 """
 import os
@@ -17,7 +17,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libtsamd.so")
 MAX_K = 32
-SCHED_MAX_K = 8  # kResidentMaxK (csrc/tsamd_kernels.h)
+SCHED_MAX_K = 32  # kResidentMaxK (csrc/tsamd_resident_kernels.h)
 HEADERS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(ROOT, "include", "tsamd.h")]
 # -amdgpu-kernarg-preload-count: the leading scalar kernel arguments (ts_pass: control block, partial rows, weights,
 # geometry) arrive in SGPRs with the wave instead of through a kernel-argument load (gfx950 supports it)
@@ -38,7 +38,7 @@ def _units():
     for k in range(1, MAX_K + 1):
         units.append((os.path.join(OBJ_DIR, f"inst_k{k}.o"), os.path.join(CSRC, "tsamd_inst.hip"),
                       [f"-DTSAMD_K={k}"]))
-    # the whole-schedule kernel (K <= 8): its own units, without machine LICM (see csrc/tsamd_sched.hip)
+    # the whole-schedule kernel: its own units, without machine LICM (see csrc/tsamd_sched.hip)
     for k in range(1, SCHED_MAX_K + 1):
         units.append((os.path.join(OBJ_DIR, f"sched_k{k}.o"), os.path.join(CSRC, "tsamd_sched.hip"),
                       [f"-DTSAMD_K={k}", "-mllvm", "-disable-machine-licm"]))

@@ -18,6 +18,7 @@
 #define TSAMD_MAIN_TU 1
 #include "tsamd_generic_kernels.h"
 #include "tsamd_kernels.h"
+#include "tsamd_resident_kernels.h"
 #include "tsamd_wide_kernels.h"
 
 using namespace tsamd;
@@ -134,8 +135,22 @@ struct tsamd_ctx {
   bool graphs_ready = false;
   uint64_t q = 0;  // kernels of the state-machine sequence launched so far (parity = q & 1)
   uint32_t prev_rows = 0;  // grid of the last pass kernel enqueued (row-count hint for the next)
-  // pinned host copies of schedules whose upload may still be in flight (recycled at tsamd_synchronize)
-  std::vector<std::pair<uint32_t *, size_t>> sched_busy, sched_free;
+  // Pinned host copies of the schedules enqueued since the stream was last known idle, in order (the kernels read
+  // them; recycled by settle()).  Also the journal a failed resident launch is replayed from: mode = how the entry was
+  // launched (0 per pass, 1 per SNP, 2 per schedule), serial0 = launch serial of its first resident launch.
+  struct Journal {
+    uint32_t *ent;
+    size_t cap;
+    uint32_t n, serial0;
+    int mode;
+  };
+  std::vector<Journal> journal;
+  std::vector<std::pair<uint32_t *, size_t>> sched_free;
+  uint32_t launch_serial = 0;   // resident launches so far (ts_resident / ts_schedule carry it; a failing one reports it)
+  bool recovering = false;
+  uint32_t recoveries = 0;      // times a resident launch gave up at its entry and the schedule was replayed launch per pass
+  hipStream_t aux_stream = nullptr;      // tsamd_debug_occupy
+  unsigned long long *h_occupy = nullptr;  // pinned: its kernel has started
   std::string err;
 };
 
@@ -166,21 +181,18 @@ int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
   if (!(ctx)) return TSAMD_EINVAL
 
 // launchers of the K-specialised kernels, one per translation unit (tsamd_inst.hip)
-#define TSAMD_DECL(k)                                                                              \
-  void launch_k##k(int, uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, uint32_t); \
-  int first_blocks_per_cu_k##k(int);                                                               \
-  int resident_blocks_per_cu_k##k();
-#define TSAMD_SCHED_DECL(k)                                                                       \
-  void launch_schedule_k##k(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t); \
+#define TSAMD_DECL(k)                                                                                        \
+  void launch_k##k(int, uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, uint32_t, uint32_t); \
+  int first_blocks_per_cu_k##k(int);                                                                         \
+  int resident_blocks_per_cu_k##k();                                                                         \
+  void launch_schedule_k##k(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t, uint32_t); \
   int schedule_blocks_per_cu_k##k();
-#define TSAMD_SCHED_K(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #define TSAMD_ALL_K(X)                                                                             \
   X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)     \
   X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 }  // namespace
 namespace tsamd {
-TSAMD_ALL_K(TSAMD_DECL)
-TSAMD_SCHED_K(TSAMD_SCHED_DECL)  // tsamd_sched.hip, K <= kResidentMaxK
+TSAMD_ALL_K(TSAMD_DECL)  // tsamd_inst.hip and tsamd_sched.hip, one pair of translation units per K
 }
 namespace {
 #define TSAMD_ENTRY(k) tsamd::launch_k##k,
@@ -189,12 +201,12 @@ const LaunchFn kLaunchers[TSAMD_SPECIALIZED_K + 1] = {nullptr, TSAMD_ALL_K(TSAMD
 int (*const kFirstBlocksPerCu[TSAMD_SPECIALIZED_K + 1])(int) = {nullptr, TSAMD_ALL_K(TSAMD_OCC_ENTRY)};
 #define TSAMD_RES_ENTRY(k) tsamd::resident_blocks_per_cu_k##k,
 int (*const kResidentBlocksPerCu[TSAMD_SPECIALIZED_K + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_RES_ENTRY)};
-static_assert(kResidentMaxK == 8, "TSAMD_SCHED_K lists K = 1 .. kResidentMaxK");
-typedef void (*ScheduleFn)(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t);
+static_assert(kResidentMaxK == TSAMD_SPECIALIZED_K, "TSAMD_ALL_K lists K = 1 .. kResidentMaxK");
+typedef void (*ScheduleFn)(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t, uint32_t);
 #define TSAMD_SCHED_ENTRY(k) tsamd::launch_schedule_k##k,
-const ScheduleFn kScheduleLaunchers[kResidentMaxK + 1] = {nullptr, TSAMD_SCHED_K(TSAMD_SCHED_ENTRY)};
+const ScheduleFn kScheduleLaunchers[kResidentMaxK + 1] = {nullptr, TSAMD_ALL_K(TSAMD_SCHED_ENTRY)};
 #define TSAMD_SCHED_OCC_ENTRY(k) tsamd::schedule_blocks_per_cu_k##k,
-int (*const kScheduleBlocksPerCu[kResidentMaxK + 1])() = {nullptr, TSAMD_SCHED_K(TSAMD_SCHED_OCC_ENTRY)};
+int (*const kScheduleBlocksPerCu[kResidentMaxK + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_SCHED_OCC_ENTRY)};
 
 __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -220,9 +232,9 @@ int enqueue_pass(tsamd_ctx *c, uint32_t pass) {
       hipLaunchKernelGGL((ts_pass_wide<false>), dim3(c->grid_first), dim3(kWideBlock), 0, c->stream, c->p, par_arg, hint);
     c->prev_rows = c->grid_first;
   } else if (first)
-    kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p, par_arg, hint);
+    kLaunchers[c->cfg.k](kLaunchFirst, c->grid_first, c->first_vec == 2 ? 1u : 0u, c->stream, c->p, par_arg, hint, 0u);
   else
-    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p, par_arg, hint);
+    kLaunchers[c->cfg.k](kLaunchPass, c->grid, c->block, c->stream, c->p, par_arg, hint, 0u);
   if (!c->wide) c->prev_rows = first ? c->grid_first : c->grid;
   if (c->split && !c->p2p) {  // (peer-to-peer: every workgroup has already pushed its row to every rank)
     hipLaunchKernelGGL(ts_reduce_rows, dim3(1), dim3(256), 0, c->stream, c->p, par);
@@ -285,8 +297,8 @@ int enqueue_snp(tsamd_ctx *c) {
   if (c->resident) {  // every plain pass of the SNP in one launch
     if (rc == TSAMD_OK) {
       const uint32_t par = next_parity(c);
-      kLaunchers[c->cfg.k](kLaunchResident, c->grid, (uint32_t)kResidentBlock, c->stream, c->p, par, c->prev_rows);
-      c->prev_rows = c->grid;
+      kLaunchers[c->cfg.k](kLaunchResident, c->sched_grid, c->sched_chunk, c->stream, c->p, par, c->prev_rows, c->launch_serial++);
+      c->prev_rows = c->sched_grid;
     }
   } else {
     for (uint32_t i = 1; rc == TSAMD_OK && i < c->cfg.max_inner; ++i) rc = enqueue_pass(c, i);
@@ -419,9 +431,31 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
   geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", first_target), p.chunk_first, c->grid_first);
 }
 
+// Launch geometry of the resident kernels for a shard of `npad` padded individuals on at most `cap` workgroups (all
+// resident at once): items of resident_vec(K) individuals, a whole number of 256-thread rounds per workgroup.  False
+// when the shard does not fit resident_items(K) items per thread.
+bool resident_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, uint32_t *chunk) {
+  if (cap == 0u || (int)k > kResidentMaxK) return false;
+  const uint32_t nitems = npad / (uint32_t)resident_vec((int)k);
+  uint32_t ch = (nitems + cap - 1u) / cap;
+  ch = (ch + (uint32_t)kResidentBlock - 1u) / (uint32_t)kResidentBlock * (uint32_t)kResidentBlock;
+  if (ch > (uint32_t)(resident_items((int)k) * kResidentBlock)) return false;
+  *chunk = ch;
+  *grid = (nitems + ch - 1u) / ch;
+  return true;
+}
+
+bool alloc_res(tsamd_ctx *c) {
+  if (c->res) return true;
+  if (hipMalloc((void **)&c->res, sizeof(ResXchg)) != hipSuccess) return false;
+  if (hipMemsetAsync(c->res, 0, sizeof(ResXchg), c->stream) != hipSuccess) return false;
+  c->p.res = c->res;
+  return true;
+}
+
 // ts_schedule on a shard: one launch per rank and schedule, weights resident, level 2 of the in-launch exchange across
 // the ranks (Xchg::res_sums).  Every rank must reach the same verdict, so it depends only on the configuration: up to 8
-// ranks, K <= 8, the reference's default learning-rate exponent, every rank's shard fits the register file of at most
+// ranks, the reference's default learning-rate exponent, every rank's shard fits the register file of at most
 // min(256, CUs / device_share) workgroups and fills at least 8 of them (all 8 groups of every rank then post a sum).
 void choose_sharded_schedule(tsamd_ctx *c) {
   const tsamd_config &cfg = c->cfg;
@@ -435,23 +469,15 @@ void choose_sharded_schedule(tsamd_ctx *c) {
   if (cap < (uint32_t)kResGroups) return;
   uint32_t my_grid = 0, my_chunk = 0;
   for (uint32_t r = 0; r < cfg.world; ++r) {
-    uint32_t b = 0, cnt = 0;
+    uint32_t b = 0, cnt = 0, grid = 0, chunk = 0;
     tsamd_shard_range(cfg.n, r, cfg.world, &b, &cnt);
-    const uint32_t npairs = (cnt + 511u) / 512u * 256u;
-    uint32_t chunk = (npairs + cap - 1u) / cap;
-    chunk = (chunk + (uint32_t)kResidentBlock - 1u) / (uint32_t)kResidentBlock * (uint32_t)kResidentBlock;
-    const uint32_t grid = (npairs + chunk - 1u) / chunk;
-    if (chunk > (uint32_t)(kResidentItems * kResidentBlock) || grid < (uint32_t)kResGroups) return;
+    if (!resident_geometry(cfg.k, (cnt + 511u) / 512u * 512u, cap, &grid, &chunk) || grid < (uint32_t)kResGroups) return;
     if (r == cfg.rank) {
       my_grid = grid;
       my_chunk = chunk;
     }
   }
-  if (!c->res) {
-    if (hipMalloc((void **)&c->res, sizeof(ResXchg)) != hipSuccess) return;
-    if (hipMemsetAsync(c->res, 0, sizeof(ResXchg), c->stream) != hipSuccess) return;
-    c->p.res = c->res;
-  }
+  if (!alloc_res(c)) return;
   c->sched_grid = my_grid;
   c->sched_chunk = my_chunk;
   c->persistent = c->can_persistent = true;
@@ -464,8 +490,11 @@ void activate_xchg(tsamd_ctx *c) {
   c->p.xchg_world = c->cfg.world;
   c->p.xchg_rank = c->cfg.rank;
   c->p.rows_from_lt = 0u;
-  c->p.xchg_test_delay = env_u32("TSAMD_TEST_XCHG_DELAY_US", 0) * 100u;  // test hooks (tsamd_device.h)
-  c->p.xchg_test_noguard = env_u32("TSAMD_TEST_XCHG_NOGUARD", 0);
+  // test hooks (tsamd_device.h): honoured only by a context created with TSAMD_FLAG_TEST_HOOKS -- a stray environment
+  // variable must never switch the slot-reuse guard of a production run off
+  const bool hooks = (c->cfg.flags & TSAMD_FLAG_TEST_HOOKS) != 0u;
+  c->p.xchg_test_delay = hooks ? env_u32("TSAMD_TEST_XCHG_DELAY_US", 0) * 100u : 0u;
+  c->p.xchg_test_noguard = hooks ? env_u32("TSAMD_TEST_XCHG_NOGUARD", 0) : 0u;
   c->split = true;
   c->resident = c->persistent = c->can_resident = c->can_persistent = false;
   c->p2p = true;
@@ -524,6 +553,16 @@ int check_locs(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs) {
 
 extern "C" {
 
+// Wait for the stream, deal with what the kernels reported through the pinned error word (a resident launch that gave
+// up at its entry is replayed one launch per pass), recycle the journal.  Defined with tsamd_run_schedule.
+static int settle(tsamd_ctx *c);
+// ... before anything that reads or replaces state while schedules may still be in flight
+#define SETTLE(c)                          \
+  do {                                     \
+    if (!(c)->journal.empty())             \
+      if (int rc_ = settle(c)) return rc_; \
+  } while (0)
+
 int tsamd_abi_version(void) { return TSAMD_ABI_VERSION; }
 
 void tsamd_default_config(tsamd_config *cfg, uint32_t n, uint32_t l, uint32_t k) {
@@ -579,6 +618,11 @@ void tsamd_destroy(tsamd_ctx *c) {
   hipFree(c->d_sched);
   hipFree(c->res);
   if (c->h_error) hipHostFree(c->h_error);
+  if (c->aux_stream) {
+    hipStreamSynchronize(c->aux_stream);
+    hipStreamDestroy(c->aux_stream);
+  }
+  if (c->h_occupy) hipHostFree(c->h_occupy);
   hipFree(c->d_hids);
   hipFree(c->d_hy);
   hipFree(c->d_hterms);
@@ -587,7 +631,7 @@ void tsamd_destroy(tsamd_ctx *c) {
   hipFree(c->d_fold_orig);
   hipFree(c->d_hsums);
   if (c->h_stage) hipHostFree(c->h_stage);
-  for (auto &b : c->sched_busy) hipHostFree(b.first);
+  for (auto &j : c->journal) hipHostFree(j.ent);
   for (auto &b : c->sched_free) hipHostFree(b.first);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -666,23 +710,31 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   }
   p.rows_from_lt = c->split ? 1u : 0u;
   p.sweep_alternate = env_u32("TSAMD_SWEEP", 1) ? 1u : 0u;
+  p.probe_ticks = std::max<uint32_t>(1u, env_u32("TSAMD_PROBE_MS", 100)) * 100000u;  // (10 ns ticks)
   {
-    // Resident plain passes (ts_resident): one GPU, K <= 8, the shard's weights fit the register file
-    // (at most eight items per thread of a 256-thread workgroup) and every workgroup can be resident at once.
+    // The resident kernels: one GPU (a sharded context decides in choose_sharded_schedule), K <= 32, the shard's
+    // weights fit the register file (resident_items(K) items per thread of a 256-thread workgroup) and every workgroup
+    // can be resident at once -- which the kernels verify for themselves at the start of every launch.
     hipDeviceProp_t prop;
     const int cus = hipGetDeviceProperties(&prop, c->dev) == hipSuccess ? prop.multiProcessorCount : 0;
-    c->resident = !c->wide && !c->split && cfg->world == 1 && (int)cfg->k <= kResidentMaxK &&
-                  p.chunk <= (uint32_t)(kResidentItems * kResidentBlock) && (int)c->grid <= cus && c->grid <= (uint32_t)(kResGroups * kResMembers) &&
-                  cfg->max_inner >= 2 && cfg->max_inner <= 200 && env_u32("TSAMD_RESIDENT", 1) != 0u &&
-                  kResidentBlocksPerCu[cfg->k]() >= 1;
+    c->sched_grid = c->grid;
+    c->sched_chunk = p.chunk;
+    bool fits;
+    if (cfg->k <= 8u)  // (items are pairs: the plain pass' own geometry -- TSAMD_GRID / TSAMD_BLOCK apply)
+      fits = !c->wide && p.chunk <= (uint32_t)(resident_items((int)cfg->k) * kResidentBlock) && (int)c->grid <= cus &&
+             c->grid <= (uint32_t)(kResGroups * kResMembers);
+    else
+      fits = !c->wide && cus > 0 && env_u32("TSAMD_GRID", 0) == 0u &&
+             resident_geometry(cfg->k, c->npad, std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)cus), &c->sched_grid,
+                               &c->sched_chunk);
+    c->resident = fits && !c->split && cfg->world == 1 && cfg->max_inner >= 2 && cfg->max_inner <= 200 &&
+                  env_u32("TSAMD_RESIDENT", 1) != 0u && kResidentBlocksPerCu[cfg->k]() >= 1;
     // ... and then, with the reference's default learning-rate exponent (the kernel carries no pow()), the whole
     // schedule in one launch
     c->persistent = c->resident && cfg->nodekappa == 0.5 && env_u32("TSAMD_PERSISTENT", 1) != 0u &&
                     kScheduleBlocksPerCu[cfg->k]() >= 1;
     c->can_resident = c->resident;
     c->can_persistent = c->persistent;
-    c->sched_grid = c->grid;
-    c->sched_chunk = p.chunk;
   }
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
@@ -701,11 +753,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   CREATE_TRY(hipHostMalloc((void **)&c->h_error, (3 + TSAMD_PASS_HIST_BINS) * sizeof(unsigned long long), hipHostMallocDefault));
   memset(c->h_error, 0, (3 + TSAMD_PASS_HIST_BINS) * sizeof(unsigned long long));
   p.host_error = c->h_error;
-  if (c->resident) {
-    CREATE_TRY(hipMalloc((void **)&c->res, sizeof(ResXchg)));
-    CREATE_TRY(hipMemsetAsync(c->res, 0, sizeof(ResXchg), c->stream));
-    p.res = c->res;
-  }
+  if (c->resident && !alloc_res(c)) CREATE_TRY(hipErrorOutOfMemory);
   CREATE_TRY(hipMemsetAsync(p.bed, 0x55, L * p.colstride, c->stream));  // all missing
   CREATE_TRY(hipMemsetAsync(p.cnt, 0, np * sizeof(uint32_t), c->stream));
   CREATE_TRY(hipMemsetAsync(p.ctl, 0, sizeof(Ctl), c->stream));
@@ -741,6 +789,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
 static int upload_bed_impl(tsamd_ctx *c, const uint8_t *payload, uint64_t bytes_per_snp, uint32_t first_loc,
                            uint32_t n_locs, bool wait) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!payload) return fail(c, TSAMD_EINVAL, "null payload");
   if (bytes_per_snp != ((uint64_t)c->cfg.n + 3) / 4)
     return fail(c, TSAMD_EINVAL, "bytes_per_snp %llu != ceil(n/4) = %llu", (unsigned long long)bytes_per_snp,
@@ -812,6 +861,7 @@ int tsamd_upload_bed_async(tsamd_ctx *c, const uint8_t *payload, uint64_t bytes_
 int tsamd_upload_bed_indiv_major(tsamd_ctx *c, const uint8_t *payload, uint64_t bytes_per_indiv, uint32_t first_indiv,
                                  uint32_t n_indivs) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!payload) return fail(c, TSAMD_EINVAL, "null payload");
   if (bytes_per_indiv != ((uint64_t)c->cfg.l + 3) / 4)
     return fail(c, TSAMD_EINVAL, "bytes_per_indiv %llu != ceil(l/4) = %llu", (unsigned long long)bytes_per_indiv,
@@ -869,6 +919,7 @@ void tsamd_host_free(void *ptr) {
 
 int tsamd_genotype_counts(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs, uint64_t counts[4]) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!counts) return fail(c, TSAMD_EINVAL, "null output");
   if (int rc = check_locs(c, first_loc, n_locs)) return rc;
   for (int i = 0; i < 4; ++i) counts[i] = 0;
@@ -894,6 +945,7 @@ int tsamd_genotype_counts(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs, uin
 
 int tsamd_download_bed(tsamd_ctx *c, uint32_t loc, uint8_t *out, uint64_t out_bytes) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (int rc = check_locs(c, loc, 1)) return rc;
   const size_t nbytes = ((size_t)c->n_local + 3) / 4;
   if (!out || out_bytes < nbytes) return fail(c, TSAMD_EINVAL, "output buffer too small (%llu < %zu)",
@@ -906,6 +958,7 @@ int tsamd_download_bed(tsamd_ctx *c, uint32_t loc, uint8_t *out, uint64_t out_by
 
 int tsamd_set_heldout(tsamd_ctx *c, uint32_t loc, const uint32_t *indivs, uint32_t count) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (int rc = check_locs(c, loc, 1)) return rc;
   if (count && !indivs) return fail(c, TSAMD_EINVAL, "null indivs");
   HeldLoc &h = c->held[loc];
@@ -977,6 +1030,7 @@ int tsamd_set_heldout(tsamd_ctx *c, uint32_t loc, const uint32_t *indivs, uint32
 
 int tsamd_set_gamma(tsamd_ctx *c, const double *gamma) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!gamma) return fail(c, TSAMD_EINVAL, "null gamma");
   for (size_t i = 0; i < (size_t)c->n_local * c->cfg.k; ++i)
     if (!(gamma[i] > 0.0) || !std::isfinite(gamma[i])) return fail(c, TSAMD_EINVAL, "gamma[%zu] must be positive and finite", i);
@@ -985,7 +1039,7 @@ int tsamd_set_gamma(tsamd_ctx *c, const double *gamma) {
   if (c->wide)
     hipLaunchKernelGGL(ts_refresh_w_wide, dim3((c->npad + 255) / 256), dim3(256), 0, c->stream, c->p);
   else
-    kLaunchers[c->cfg.k](kLaunchRefresh, 0, 0, c->stream, c->p, 0, 0);
+    kLaunchers[c->cfg.k](kLaunchRefresh, 0, 0, c->stream, c->p, 0, 0, 0u);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSAMD_OK;
@@ -993,18 +1047,21 @@ int tsamd_set_gamma(tsamd_ctx *c, const double *gamma) {
 
 int tsamd_get_gamma(tsamd_ctx *c, double *out) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!out) return fail(c, TSAMD_EINVAL, "null output");
   HIP_TRY(c, hipSetDevice(c->dev));
   return export_indiv(c, 0, out);
 }
 int tsamd_get_theta(tsamd_ctx *c, double *out) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!out) return fail(c, TSAMD_EINVAL, "null output");
   HIP_TRY(c, hipSetDevice(c->dev));
   return export_indiv(c, 1, out);
 }
 int tsamd_get_elogtheta(tsamd_ctx *c, double *out) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!out) return fail(c, TSAMD_EINVAL, "null output");
   HIP_TRY(c, hipSetDevice(c->dev));
   return export_indiv(c, 2, out);
@@ -1012,6 +1069,7 @@ int tsamd_get_elogtheta(tsamd_ctx *c, double *out) {
 
 int tsamd_set_counts(tsamd_ctx *c, const uint32_t *cn) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!cn) return fail(c, TSAMD_EINVAL, "null counts");
   HIP_TRY(c, hipSetDevice(c->dev));
   HIP_TRY(c, hipMemcpyAsync(c->p.cnt, cn, (size_t)c->n_local * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -1020,6 +1078,7 @@ int tsamd_set_counts(tsamd_ctx *c, const uint32_t *cn) {
 }
 int tsamd_get_counts(tsamd_ctx *c, uint32_t *cn) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!cn) return fail(c, TSAMD_EINVAL, "null counts");
   HIP_TRY(c, hipSetDevice(c->dev));
   HIP_TRY(c, hipMemcpyAsync(cn, c->p.cnt, (size_t)c->n_local * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1029,6 +1088,7 @@ int tsamd_get_counts(tsamd_ctx *c, uint32_t *cn) {
 
 int tsamd_set_lambda(tsamd_ctx *c, uint32_t loc, const double *lambda) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!lambda) return fail(c, TSAMD_EINVAL, "null lambda");
   if (int rc = check_locs(c, loc, 1)) return rc;
   const size_t J = 2 * (size_t)c->cfg.k;
@@ -1043,6 +1103,7 @@ int tsamd_set_lambda(tsamd_ctx *c, uint32_t loc, const double *lambda) {
 
 static int export_loc(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs, int mode, double *out) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!out) return fail(c, TSAMD_EINVAL, "null output");
   if (int rc = check_locs(c, first_loc, n_locs)) return rc;
   if (n_locs == 0) return TSAMD_OK;
@@ -1082,55 +1143,15 @@ int tsamd_get_elogbeta(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs, double
   return export_loc(c, first_loc, n_locs, 1, out);
 }
 
-int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_mode) {
-  CHECK_CTX(c);
-  if (n == 0) return TSAMD_OK;
-  if (!locs) return fail(c, TSAMD_EINVAL, "null schedule");
-  if (c->cfg.world > 1 && !c->comm && !c->p2p)
-    return fail(c, TSAMD_ECOMM, "context is shard %u of %u but neither tsamd_comm_init nor tsamd_p2p_connect has been called",
-                c->cfg.rank, c->cfg.world);
-  for (uint32_t i = 0; i < n; ++i)
-    if (locs[i] >= c->cfg.l) return fail(c, TSAMD_EINVAL, "schedule[%u] = %u >= l", i, locs[i]);
-  HIP_TRY(c, hipSetDevice(c->dev));
-  // the schedule goes up through a pinned buffer: the copy is then really asynchronous
-  std::pair<uint32_t *, size_t> stage{nullptr, 0};
-  for (size_t i = 0; i < c->sched_free.size(); ++i)
-    if (c->sched_free[i].second >= n) {
-      stage = c->sched_free[i];
-      c->sched_free.erase(c->sched_free.begin() + i);
-      break;
-    }
-  if (!stage.first) {
-    size_t cap = 1024;
-    while (cap < n) cap *= 2;
-    // (portable + mapped: ts_schedule reads the entries straight from this buffer, on whichever device the context uses)
-    HIP_TRY(c, hipHostMalloc((void **)&stage.first, cap * sizeof(uint32_t), hipHostMallocPortable | hipHostMallocMapped));
-    stage.second = cap;
-  }
-  c->sched_busy.push_back(stage);
-  uint32_t *ent = stage.first;
-  for (uint32_t i = 0; i < n; ++i) ent[i] = locs[i] | (hol_mode ? 0x80000000u : 0u);
-  if (!c->persistent && n > c->sched_cap) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    hipFree(c->d_sched);
-    c->d_sched = nullptr;
-    c->sched_cap = 0;
-    uint32_t cap = 1024;
-    while (cap < n) cap *= 2;
-    HIP_TRY(c, hipMalloc((void **)&c->d_sched, (size_t)cap * sizeof(uint32_t)));
-    c->sched_cap = cap;  // (the kernels take the pointer from Ctl, written by ts_begin)
-  }
-  // Everything that varies per SNP is read from device memory, so captured sequences of
-  // 16, 8, 4, 2 and 1 SNPs are replayed as often as the schedule length needs (binary
-  // decomposition: nothing is padded); results are identical to eager launches bit for bit.
-  const bool use_graph = graphs_allowed(c);
-  if (use_graph)
-    if (int rc = ensure_graphs(c)) return rc;
+// Enqueue n schedule entries (location | hol << 31) that lie in pinned host memory, the way the context launches now.
+// Everything that varies per SNP is read from device memory, so in the launch-per-pass mode captured sequences of
+// 16, 8, 4, 2 and 1 SNPs are replayed as often as the schedule length needs (binary decomposition: nothing is padded);
+// results are identical to eager launches bit for bit.  eager: no graphs (the replay after a failed resident launch).
+static int enqueue_entries(tsamd_ctx *c, const uint32_t *ent, uint32_t n, bool eager) {
   if (c->persistent) {
-    // (the kernel reads the entries straight from the pinned staging buffer, one SNP ahead of their use: no copy
-    // to wait for at the start of a short schedule; the buffer is recycled at tsamd_synchronize)
-    // one launch runs the whole schedule (in pieces of kScheduleChunk SNPs): it starts from the State the
-    // previous call left and leaves one like ts_flush does -- no ts_begin, no ts_flush
+    // one launch runs the whole schedule (in pieces of kScheduleChunk SNPs): the kernel reads the entries straight from
+    // the pinned buffer, one SNP ahead of their use; it starts from the State the previous call left and leaves one like
+    // ts_flush does -- no ts_begin, no ts_flush, and none of the graphs of the launch-per-pass sequence
     for (uint32_t off = 0; off < n; off += kScheduleChunk) {
       const uint32_t len = std::min(kScheduleChunk, n - off);
       const bool prof = c->prof && c->n_ev_pass < kProfCap;
@@ -1140,7 +1161,7 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
         if (int rc = prof_event(c, c->ev_pass, 2 * c->n_ev_pass, &e)) return rc;
         HIP_TRY(c, hipEventRecord(e, c->stream));
       }
-      kScheduleLaunchers[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), ent + off, len);
+      kScheduleLaunchers[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), ent + off, len, c->launch_serial++);
       if (prof) {
         if (int rc = prof_event(c, c->ev_pass, 2 * c->n_ev_pass + 1, &e)) return rc;
         HIP_TRY(c, hipEventRecord(e, c->stream));
@@ -1150,6 +1171,19 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
     HIP_TRY(c, hipGetLastError());
     return TSAMD_OK;
   }
+  if (n > c->sched_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipFree(c->d_sched);
+    c->d_sched = nullptr;
+    c->sched_cap = 0;
+    uint32_t cap = 1024;
+    while (cap < n) cap *= 2;
+    HIP_TRY(c, hipMalloc((void **)&c->d_sched, (size_t)cap * sizeof(uint32_t)));
+    c->sched_cap = cap;  // (the kernels take the pointer from Ctl, written by ts_begin)
+  }
+  const bool use_graph = !eager && graphs_allowed(c);
+  if (use_graph)
+    if (int rc = ensure_graphs(c)) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_sched, ent, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   enqueue_begin(c, n, false);
   if (use_graph) {
@@ -1180,12 +1214,133 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   return TSAMD_OK;
 }
 
+// A resident launch gave up at its entry exchange -- not all its workgroups were resident at once: something else
+// holds compute units of this device -- with the state it started from intact, and every later kernel of the context
+// has returned without touching anything (sequence_aborted).  Lower the context to one launch per pass and replay,
+// from the journal, what the failed launch and everything enqueued after it were to do.  The reference never loses
+// the model to a scheduling hiccup either (it traps SIGTERM to save it, src/snpsamplinge.cc:454-457).
+static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
+  const uint32_t serial = (uint32_t)(code >> 34), par = (uint32_t)(code >> 33) & 1u;
+  size_t at = c->journal.size();
+  for (size_t i = 0; i < c->journal.size(); ++i) {
+    const tsamd_ctx::Journal &j = c->journal[i];
+    const uint32_t launches = j.mode == 2 ? (j.n + kScheduleChunk - 1u) / kScheduleChunk : j.mode == 1 ? j.n : 0u;
+    if (serial - j.serial0 < launches) at = i;
+  }
+  if (at == c->journal.size())
+    return fail(c, TSAMD_EHIP, "a resident launch (serial %u) gave up at its entry but is not in the journal of %zu schedule(s)", serial,
+                c->journal.size());
+  c->recovering = true;
+  const bool was_persistent = c->journal[at].mode == 2;
+  *(volatile unsigned long long *)c->h_error = 0ull;
+  HIP_TRY(c, hipMemsetAsync(c->res, 0, sizeof(ResXchg), c->stream));  // the abort word, and the granules of the failed exchange
+  c->resident = c->persistent = false;
+  destroy_graph(c);
+  c->q = par;  // the failed launch was to write the slot of this parity: the slot of the other one holds the state to go on from
+  int rc = TSAMD_OK;
+  {
+    const tsamd_ctx::Journal &j = c->journal[at];
+    if (was_persistent) {
+      const uint32_t off = (serial - j.serial0) * kScheduleChunk;
+      rc = enqueue_entries(c, j.ent + off, j.n - off, true);
+    } else {
+      // ts_resident of SNP st.idx of this schedule: its first pass is done and pending (rows in the same slot); run its
+      // plain passes, then the rest of the schedule
+      State st;
+      HIP_TRY(c, hipMemcpyAsync(&st, &c->p.ctl->st[par ^ 1u], sizeof(State), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (st.valid == 0u || st.done != 0u || st.idx >= j.n) {
+        c->recovering = false;
+        return fail(c, TSAMD_EHIP, "ts_resident gave up at its entry, but the state it started from has no pending pass (idx %u of %u)",
+                    st.idx, j.n);
+      }
+      HIP_TRY(c, hipMemcpyAsync(c->d_sched, j.ent, (size_t)j.n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      c->prev_rows = c->grid_first;
+      for (uint32_t i = 1; rc == TSAMD_OK && i < c->cfg.max_inner; ++i) rc = enqueue_pass(c, i);
+      for (uint32_t sn = st.idx + 1u; rc == TSAMD_OK && sn < j.n; ++sn) rc = enqueue_snp(c);
+      if (rc == TSAMD_OK) enqueue_flush(c);
+    }
+  }
+  for (size_t i = at + 1; rc == TSAMD_OK && i < c->journal.size(); ++i) rc = enqueue_entries(c, c->journal[i].ent, c->journal[i].n, true);
+  if (rc == TSAMD_OK) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, TSAMD_EHIP, "replay after a failed resident launch: %s", hipGetErrorString(e));
+  }
+  c->recovering = false;
+  if (rc != TSAMD_OK) return rc;
+  if (*(volatile unsigned long long *)c->h_error != 0ull) return fail(c, TSAMD_EHIP, "the replay after a failed resident launch failed too");
+  c->recoveries++;
+  fail(c, TSAMD_OK, "warning: %s could not get its %u workgroups resident at once (something else holds compute units of device %d); the "
+       "schedule was replayed one launch per pass from the unchanged state and the context stays in that mode "
+       "(tsamd_set_launch_mode raises it again)", was_persistent ? "ts_schedule" : "ts_resident", c->sched_grid, c->dev);
+  return TSAMD_OK;
+}
+
+static int settle(tsamd_ctx *c) {
+  HIP_TRY(c, hipSetDevice(c->dev));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = TSAMD_OK;
+  if (c->h_error && *(volatile unsigned long long *)c->h_error != 0ull) {  // (written by the kernel that gave up)
+    const unsigned long long err = *(volatile unsigned long long *)c->h_error;
+    const unsigned long long tag = err & 0xffffffffull;
+    if ((err & kFailIntact) != 0ull && c->cfg.world == 1u && c->res && !c->recovering)
+      rc = recover_from_failed_entry(c, err);
+    else if (c->p2p && (c->persistent || (err & kFailIntact) != 0ull))
+      rc = fail(c, TSAMD_ECOMM, "ts_schedule: the in-launch exchange across %u ranks timed out (tag %llu): a peer did not arrive, or "
+                "not all workgroups of all ranks are resident (ranks that share one device: TSAMD_DEVICE_SHARE=<ranks>)",
+                c->cfg.world, tag);
+    else if (c->p2p)
+      rc = fail(c, TSAMD_ECOMM, "peer-to-peer exchange timed out waiting for a peer (epoch %llu)", err);
+    else
+      rc = fail(c, TSAMD_EHIP, "%s: the in-launch exchange timed out in the middle of a launch (tag %llu, %u workgroups): the state is void.  "
+                "TSAMD_PERSISTENT=0 selects one launch per SNP for the plain passes, TSAMD_RESIDENT=0 one launch per pass",
+                c->persistent ? "ts_schedule" : "ts_resident", tag, c->sched_grid);
+  }
+  for (auto &j : c->journal) c->sched_free.push_back({j.ent, j.cap});
+  c->journal.clear();
+  return rc;
+}
+int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_mode) {
+  CHECK_CTX(c);
+  if (n == 0) return TSAMD_OK;
+  if (!locs) return fail(c, TSAMD_EINVAL, "null schedule");
+  if (c->cfg.world > 1 && !c->comm && !c->p2p)
+    return fail(c, TSAMD_ECOMM, "context is shard %u of %u but neither tsamd_comm_init nor tsamd_p2p_connect has been called",
+                c->cfg.rank, c->cfg.world);
+  for (uint32_t i = 0; i < n; ++i)
+    if (locs[i] >= c->cfg.l) return fail(c, TSAMD_EINVAL, "schedule[%u] = %u >= l", i, locs[i]);
+  HIP_TRY(c, hipSetDevice(c->dev));
+  // a caller that streams schedules and never synchronises must not grow the journal (pinned memory) without bound
+  // (not on a peer-to-peer context: its kernels wait for peers the caller may not have enqueued yet)
+  if (!c->p2p && c->journal.size() >= 256)
+    if (int rc = settle(c)) return rc;
+  // the schedule goes up through a pinned buffer: the copy is then really asynchronous
+  tsamd_ctx::Journal j{nullptr, 0, n, c->launch_serial, c->persistent ? 2 : c->resident ? 1 : 0};
+  for (size_t i = 0; i < c->sched_free.size(); ++i)
+    if (c->sched_free[i].second >= n) {
+      j.ent = c->sched_free[i].first;
+      j.cap = c->sched_free[i].second;
+      c->sched_free.erase(c->sched_free.begin() + i);
+      break;
+    }
+  if (!j.ent) {
+    size_t cap = 1024;
+    while (cap < n) cap *= 2;
+    // (portable + mapped: ts_schedule reads the entries straight from this buffer, on whichever device the context uses)
+    HIP_TRY(c, hipHostMalloc((void **)&j.ent, cap * sizeof(uint32_t), hipHostMallocPortable | hipHostMallocMapped));
+    j.cap = cap;
+  }
+  c->journal.push_back(j);
+  for (uint32_t i = 0; i < n; ++i) j.ent[i] = locs[i] | (hol_mode ? 0x80000000u : 0u);
+  return enqueue_entries(c, j.ent, n, false);
+}
+
 int tsamd_prepare(tsamd_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->dev));
   if (c->cfg.world > 1 && !c->comm && !c->p2p) return TSAMD_OK;  // exchange not chosen yet: nothing to capture
   if (c->persistent) {  // an empty schedule: the kernel's code object is loaded, the state only carried forward
-    kScheduleLaunchers[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), c->d_sched, 0u);
+    kScheduleLaunchers[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), c->d_sched, 0u, c->launch_serial++);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return TSAMD_OK;
@@ -1209,21 +1364,7 @@ int tsamd_prepare(tsamd_ctx *c) {
 
 int tsamd_synchronize(tsamd_ctx *c) {
   CHECK_CTX(c);
-  HIP_TRY(c, hipSetDevice(c->dev));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->sched_free.insert(c->sched_free.end(), c->sched_busy.begin(), c->sched_busy.end());
-  c->sched_busy.clear();
-  if (c->h_error && *(volatile unsigned long long *)c->h_error != 0ull) {  // (written by the kernel that gave up)
-    const unsigned long long err = *(volatile unsigned long long *)c->h_error;
-    if (c->p2p && c->persistent)
-      return fail(c, TSAMD_ECOMM, "ts_schedule: the in-launch exchange across %u ranks timed out (tag %llu): a peer did not arrive, or "
-                  "not all workgroups of all ranks are resident (ranks that share one device: TSAMD_DEVICE_SHARE=<ranks>)",
-                  c->cfg.world, err);
-    if (c->p2p) return fail(c, TSAMD_ECOMM, "peer-to-peer exchange timed out waiting for a peer (epoch %llu)", err);
-    return fail(c, TSAMD_EHIP, "%s: the in-launch exchange timed out (tag %llu): are all %u workgroups resident?  "
-                "TSAMD_PERSISTENT=0 selects one launch per SNP for the plain passes, TSAMD_RESIDENT=0 one launch per pass",
-                c->persistent ? "ts_schedule" : "ts_resident", err, c->grid);
-  }
+  if (int rc = settle(c)) return rc;
   if (c->prof) {
     for (uint32_t i = 0; i < c->n_ev_pass; ++i) {
       float ms = 0;
@@ -1258,8 +1399,7 @@ int tsamd_snp_update(tsamd_ctx *c, uint32_t loc, int hol_mode, uint32_t *inner_i
 int tsamd_total_passes(tsamd_ctx *c, uint64_t *passes) {
   CHECK_CTX(c);
   if (!passes) return fail(c, TSAMD_EINVAL, "null output");
-  HIP_TRY(c, hipSetDevice(c->dev));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (int rc = settle(c)) return rc;
   *passes = *(volatile unsigned long long *)(c->h_error + 2);  // (mirrored by the kernel that publishes a SNP: no copy)
   return TSAMD_OK;
 }
@@ -1267,8 +1407,7 @@ int tsamd_total_passes(tsamd_ctx *c, uint64_t *passes) {
 int tsamd_pass_histogram(tsamd_ctx *c, uint64_t hist[TSAMD_PASS_HIST_BINS]) {
   CHECK_CTX(c);
   if (!hist) return fail(c, TSAMD_EINVAL, "null output");
-  HIP_TRY(c, hipSetDevice(c->dev));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (int rc = settle(c)) return rc;
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "histogram element size");
   for (int b = 0; b < TSAMD_PASS_HIST_BINS; ++b) hist[b] = *(volatile unsigned long long *)(c->h_error + 3 + b);
   return TSAMD_OK;
@@ -1277,6 +1416,7 @@ int tsamd_pass_histogram(tsamd_ctx *c, uint64_t hist[TSAMD_PASS_HIST_BINS]) {
 int tsamd_clear_pending(tsamd_ctx *c) {
   CHECK_CTX(c);
   HIP_TRY(c, hipSetDevice(c->dev));
+  SETTLE(c);
   enqueue_begin(c, 0xffffffffu, true);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TSAMD_OK;
@@ -1517,6 +1657,7 @@ int tsamd_run_schedule_all(tsamd_ctx *const *ctxs, uint32_t count, const uint32_
 int tsamd_synth_genotypes(tsamd_ctx *c, const double *theta, const double *beta, uint32_t first_loc,
                           uint32_t n_locs, uint64_t seed, double missing_rate) {
   CHECK_CTX(c);
+  SETTLE(c);
   if (!theta || !beta) return fail(c, TSAMD_EINVAL, "null theta/beta");
   if (int rc = check_locs(c, first_loc, n_locs)) return rc;
   if (n_locs == 0) return TSAMD_OK;
@@ -1556,9 +1697,7 @@ int tsamd_profile_enable(tsamd_ctx *c, int on) {
   c->prof_pass_ms = c->prof_first_ms = 0;
   c->n_ev_pass = c->n_ev_first = 0;
   c->prof_capped = false;
-  unsigned long long v = 0;
-  HIP_TRY(c, hipMemcpy(&v, &c->p.ctl->total_passes, sizeof v, hipMemcpyDeviceToHost));
-  c->prof_passes0 = v;
+  c->prof_passes0 = *(volatile unsigned long long *)(c->h_error + 2);  // (pinned mirror; the stream is idle: tsamd_synchronize above)
   return TSAMD_OK;
 }
 
@@ -1570,8 +1709,7 @@ int tsamd_profile_read(tsamd_ctx *c, uint64_t *pass_launches, double *pass_ms_to
   // minus the first passes (a SNP that converges early leaves near-empty launches inside its
   // bracket; dividing by them would overstate the rate)
   if (!c->prof_capped && c->prof_first_n && !c->persistent) {
-    unsigned long long v = 0;
-    HIP_TRY(c, hipMemcpy(&v, &c->p.ctl->total_passes, sizeof v, hipMemcpyDeviceToHost));
+    const unsigned long long v = *(volatile unsigned long long *)(c->h_error + 2);
     const uint64_t ran = v - c->prof_passes0;
     if (ran >= c->prof_first_n && ran - c->prof_first_n <= c->prof_pass_n) c->prof_pass_n = ran - c->prof_first_n;
   }
@@ -1631,13 +1769,37 @@ int tsamd_set_launch_mode(tsamd_ctx *c, int mode) {
   CHECK_CTX(c);
   if (mode < TSAMD_LAUNCH_PER_PASS || mode > TSAMD_LAUNCH_PER_SCHEDULE) return fail(c, TSAMD_EINVAL, "launch mode %d", mode);
   if ((mode == TSAMD_LAUNCH_PER_SNP && !c->can_resident) || (mode == TSAMD_LAUNCH_PER_SCHEDULE && !c->can_persistent))
-    return fail(c, TSAMD_EUNSUPPORTED, "launch mode %d needs one GPU, k <= %d, a shard that fits the register file%s", mode,
-                kResidentMaxK, mode == TSAMD_LAUNCH_PER_SCHEDULE ? " and nodekappa == 0.5" : "");
+    return fail(c, TSAMD_EUNSUPPORTED, "launch mode %d needs k <= %d, a shard that fits the register file (%d individuals per workgroup at k = %u)%s",
+                mode, kResidentMaxK, (int)c->cfg.k <= kResidentMaxK ? resident_capacity((int)c->cfg.k) : 0, c->cfg.k,
+                mode == TSAMD_LAUNCH_PER_SCHEDULE ? " and nodekappa == 0.5" : " and one GPU");
   if (int rc = tsamd_synchronize(c)) return rc;
   const bool resident = mode >= TSAMD_LAUNCH_PER_SNP && c->can_resident, persistent = mode == TSAMD_LAUNCH_PER_SCHEDULE;
   if (resident != c->resident) destroy_graph(c);  // (captured for the other kernel sequence)
   c->resident = resident;  // (a sharded context has no launch-per-SNP mode: ts_schedule or one launch per pass)
   c->persistent = persistent;
+  return TSAMD_OK;
+}
+
+int tsamd_debug_occupy(tsamd_ctx *c, uint32_t workgroups, uint32_t milliseconds) {
+  CHECK_CTX(c);
+  if (workgroups == 0 || milliseconds > 10000u) return fail(c, TSAMD_EINVAL, "workgroups must be positive, milliseconds <= 10000");
+  HIP_TRY(c, hipSetDevice(c->dev));
+  if (!c->aux_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+  if (!c->h_occupy) HIP_TRY(c, hipHostMalloc((void **)&c->h_occupy, sizeof(unsigned long long), hipHostMallocDefault));
+  HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+  *(volatile unsigned long long *)c->h_occupy = 0ull;
+  hipLaunchKernelGGL(ts_occupy, dim3(workgroups), dim3(256), 0, c->aux_stream, (unsigned long long)milliseconds * 100000ull, c->h_occupy);
+  HIP_TRY(c, hipGetLastError());
+  for (int spin = 0; spin < 2000000 && *(volatile unsigned long long *)c->h_occupy == 0ull; ++spin) {  // until it runs (bounded: ~2 s)
+    if (hipStreamQuery(c->aux_stream) == hipSuccess) break;
+  }
+  return TSAMD_OK;
+}
+
+int tsamd_recoveries(tsamd_ctx *c, uint32_t *count) {
+  CHECK_CTX(c);
+  if (!count) return fail(c, TSAMD_EINVAL, "null output");
+  *count = c->recoveries;
   return TSAMD_OK;
 }
 

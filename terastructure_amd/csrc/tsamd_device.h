@@ -85,29 +85,14 @@ struct Xchg {
   // overwrites a slot: two slots are then always enough.
   unsigned long long prog[kMaxRanks];
   unsigned long long error;  // a bounded wait gave up
-  // ts_schedule on several GPUs: level 2 of its in-launch exchange (ResXchg below).  The leader of group g of rank r
-  // stores its group sum as granules into res_sums[parity][r * 8 + g] of EVERY rank's buffer (8-byte system-scope
-  // stores over xGMI); every workgroup then polls its own rank's copy -- local memory -- for world * 8 rows.
-  unsigned long long res_sums[2][kMaxRanks * 8][32];
+  // ts_schedule on several GPUs: level 2 of its in-launch exchange (tsamd_resident_kernels.h).  The leader of group g of
+  // rank r stores its group sum as granules into row r * 8 + g of (slot, region) of EVERY rank's buffer (8-byte
+  // system-scope stores over xGMI); every workgroup then polls its own rank's copy -- local memory -- for world * 8 rows.
+  // Laid out by ResLay<K>::rank_sums: [2 slots][2 regions][kMaxRanks * 8 rows][granules per row of the context's K <= 128]
+  unsigned long long res_sums[2 * 2 * kMaxRanks * 8 * 128];
 };
 
-// In-launch exchange of the resident plain-pass kernel (ts_resident; single GPU): per pass every
-// workgroup contributes its partial row and every workgroup gets the fixed-order total, as a
-// two-level all-reduce over 8-byte {tag, 32-bit half of a double} granules, each written by one
-// agent-scope store (the data is the flag: MI355X_MICROARCH.md, hand-off price list).
-//   level 1: the workgroups of group g = blockIdx % 8 publish rows[g][blockIdx / 8]; the group's
-//            leader (blockIdx < 8) re-reads them until every tag matches, adds them in member order
-//            and publishes sums[pass & 1][g];
-//   level 2: every workgroup re-reads the 8 leader rows and adds them in group order.
-// tag = 256 * launch epoch + pass: never repeats, so nothing is re-initialised between launches.
-constexpr int kResGroups = 8;     // (Xchg::res_sums is laid out for these two)
-constexpr int kResMembers = 32;  // workgroups per group (grid <= 256)
-constexpr int kResGran = 32;     // granules per row: 2 per value, 2K <= 16 values
-struct ResXchg {
-  unsigned long long rows[kResGroups][kResMembers][kResGran];
-  unsigned long long sums[2][kResGroups][kResGran];
-  unsigned long long abort_word;  // a bounded wait gave up (tag of the pass); later waits return at once
-};
+struct ResXchg;  // in-launch exchange buffer of the resident kernels (tsamd_resident_kernels.h)
 
 struct DevParams {
   uint8_t *bed;        // [l][colstride] 2-bit PLINK codes, shard-local, padding = missing
@@ -134,7 +119,8 @@ struct DevParams {
   unsigned long long *host_error;  // pinned host words.  [0]: a bounded in-kernel wait that gives up also writes its tag here,
                                    // so tsamd_synchronize sees it without a device-to-host copy; [1]: the inner passes of
                                    // the most recently completed SNP (Ctl::last_iters), so tsamd_snp_update needs no copy either
-  ResXchg *res;              // resident plain-pass kernel: its exchange buffer (NULL: launch per pass)
+  ResXchg *res;              // resident kernels: their exchange buffer (NULL: the context never qualified for them)
+  uint32_t probe_ticks;      // resident kernels: bound of the launch's first exchange in 10 ns ticks (are all workgroups resident?)
   uint32_t xchg_test_delay;  // test hook (TSAMD_TEST_XCHG_DELAY_US): stall between flag wait and row reads, 10 ns ticks
   uint32_t xchg_test_noguard; // test hook (TSAMD_TEST_XCHG_NOGUARD): skip the slot-reuse guard (to show the test sees the hazard)
   double alpha, eta0, eta1, nodetau0, nodekappa, gamma_scale, thresh;

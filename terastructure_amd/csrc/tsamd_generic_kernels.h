@@ -311,4 +311,15 @@ __global__ __launch_bounds__(kBlock) void ts_synth(uint8_t *bed, uint64_t colstr
   }
 }
 
+// tsamd_debug_occupy: workgroups that hold a compute unit each for `ticks` (10 ns): 96 KB of LDS, so that no workgroup of
+// the resident kernels (one per compute unit, ~140 KB of LDS) fits beside one.  Tells the host when it runs.
+__global__ __launch_bounds__(256) void ts_occupy(unsigned long long ticks, unsigned long long *started) {
+  __shared__ unsigned long long s_hold[12288];
+  s_hold[threadIdx.x] = ticks;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < s_hold[(threadIdx.x * 7u) % 256u]) __builtin_amdgcn_s_sleep(32);
+}
+
 }  // namespace tsamd

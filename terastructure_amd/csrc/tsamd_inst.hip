@@ -1,7 +1,7 @@
 // One instantiation unit of the K-specialised kernels: compiled once per K with
 // -DTSAMD_K=<k> (terastructure_amd/build.py), so the builds run in parallel and the
 // kernels see K as a compile-time constant.
-#include "tsamd_kernels.h"
+#include "tsamd_resident_kernels.h"
 
 #ifndef TSAMD_K
 #error "compile with -DTSAMD_K=<populations>"
@@ -16,8 +16,9 @@
 
 namespace tsamd {
 
+// (kLaunchResident: `block` carries the chunk -- items per workgroup -- and `serial` the host's launch serial)
 void TSAMD_CAT(launch_k, TSAMD_K)(int which, uint32_t grid, uint32_t block, hipStream_t stream, const DevParams &p,
-                                  uint32_t par, uint32_t nrows_hint) {
+                                  uint32_t par, uint32_t nrows_hint, uint32_t serial) {
   constexpr int K = TSAMD_K;
   switch (which) {
     case kLaunchPass:
@@ -36,8 +37,8 @@ void TSAMD_CAT(launch_k, TSAMD_K)(int which, uint32_t grid, uint32_t block, hipS
       break;
     case kLaunchResident:
       if constexpr (K <= kResidentMaxK)
-        hipLaunchKernelGGL((ts_resident<K>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.partials, p.w, p.npad, p.chunk, par,
-                           nrows_hint, p.res, p);
+        hipLaunchKernelGGL((ts_resident<K>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.partials, p.w, p.npad, block, par,
+                           nrows_hint, p.res, serial, p);
       break;
     default:
       hipLaunchKernelGGL((ts_refresh_w<K>), dim3((p.npairs + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, p);
@@ -45,7 +46,7 @@ void TSAMD_CAT(launch_k, TSAMD_K)(int which, uint32_t grid, uint32_t block, hipS
   }
 }
 
-// can a 512-thread workgroup of the resident plain-pass kernel run on a compute unit (register budget)?
+// can a workgroup of the resident plain-pass kernel run on a compute unit (register budget)?
 int TSAMD_CAT(resident_blocks_per_cu_k, TSAMD_K)() {
   constexpr int K = TSAMD_K;
   if constexpr (K <= kResidentMaxK) {

@@ -1,8 +1,8 @@
-// The whole-schedule kernel ts_schedule<K> (tsamd_kernels.h), one translation unit per K <= kResidentMaxK,
+// The whole-schedule kernel ts_schedule<K> (tsamd_resident_kernels.h), one translation unit per K <= kResidentMaxK,
 // compiled with -DTSAMD_K=<k> and `-mllvm -disable-machine-licm` (terastructure_amd/build.py): the kernel
 // is one loop over the schedule around fully unrolled sweeps, and loop-invariant code motion would hoist
 // a few hundred addresses and constants out of that loop into registers the kernel needs for the weights.
-#include "tsamd_kernels.h"
+#include "tsamd_resident_kernels.h"
 
 #ifndef TSAMD_K
 #error "compile with -DTSAMD_K=<populations>"
@@ -12,18 +12,24 @@
 
 namespace tsamd {
 
-static_assert(TSAMD_K <= kResidentMaxK, "ts_schedule holds the shard's weights in registers: K <= 8");
+static_assert(TSAMD_K <= kResidentMaxK, "ts_schedule holds the shard's weights in registers");
+constexpr bool kAlwaysPartial = (TSAMD_K) > 8;
+static_assert(offsetof(ResXchg, abort_word) == 0, "sequence_aborted() reads the first word of the buffer");
+static_assert(sizeof(((Xchg *)nullptr)->res_sums) / sizeof(unsigned long long) >= 2u * 2u * kMaxRanks * kResGroups * ResLay<TSAMD_K>::GR,
+              "Xchg::res_sums holds two slots x two regions of world x 8 rows");
 
 // n entries at `sched` (pinned host or device memory), starting from and leaving the State of parity par.
-// A chunk that fills all eight items of its threads runs the kernel without the skip-unused-items branches; a sharded
+// A chunk that fills all items of its threads runs the kernel without the skip-unused-items branches; a sharded
 // context (p.xchg_world ranks connected peer to peer) runs the instantiation whose level 2 spans the ranks' group
 // leaders (8 row pairs per lane for up to 2 ranks, 16 for up to 4, 32 for up to 8).
-#define TSAMD_SCHED_LAUNCH(PARTIAL, WR)                                                                                            \
-  hipLaunchKernelGGL((ts_schedule<TSAMD_K, PARTIAL, WR>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.w, p.npad, chunk, par, \
-                     sched, n, p.res, p)
+#define TSAMD_SCHED_LAUNCH(PARTIAL, WR)                                                                                               \
+  hipLaunchKernelGGL((ts_schedule<TSAMD_K, (PARTIAL) || kAlwaysPartial, WR>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.w, p.npad, \
+                     chunk, par, sched, n, p.res, serial, p)
 void TSAMD_CAT(launch_schedule_k, TSAMD_K)(uint32_t grid, uint32_t chunk, hipStream_t stream, const DevParams &p, uint32_t par,
-                                           const uint32_t *sched, uint32_t n) {
-  const bool partial = chunk <= (uint32_t)((kResidentItems - 1) * kResidentBlock);
+                                           const uint32_t *sched, uint32_t n, uint32_t serial) {
+  // (K > 8: always the instantiation with the skip branches -- without them the scheduler moves the items' loads so far
+  // ahead that the kernel no longer fits the register file)
+  const bool partial = kAlwaysPartial || chunk <= (uint32_t)((resident_items(TSAMD_K) - 1) * kResidentBlock);
   const uint32_t world = p.xchg_world;
   if (world == 0u) {
     if (partial) TSAMD_SCHED_LAUNCH(true, 0); else TSAMD_SCHED_LAUNCH(false, 0);
@@ -44,13 +50,13 @@ int TSAMD_CAT(schedule_blocks_per_cu_k, TSAMD_K)() {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kResidentBlock, 0) != hipSuccess) nb = 0;
     worst = nb < worst ? nb : worst;
   };
-  probe(ts_schedule<TSAMD_K, false, 0>);
+  probe(ts_schedule<TSAMD_K, kAlwaysPartial, 0>);
   probe(ts_schedule<TSAMD_K, true, 0>);
-  probe(ts_schedule<TSAMD_K, false, 8>);
+  probe(ts_schedule<TSAMD_K, kAlwaysPartial, 8>);
   probe(ts_schedule<TSAMD_K, true, 8>);
-  probe(ts_schedule<TSAMD_K, false, 16>);
+  probe(ts_schedule<TSAMD_K, kAlwaysPartial, 16>);
   probe(ts_schedule<TSAMD_K, true, 16>);
-  probe(ts_schedule<TSAMD_K, false, 32>);
+  probe(ts_schedule<TSAMD_K, kAlwaysPartial, 32>);
   probe(ts_schedule<TSAMD_K, true, 32>);
   return worst;
 }

@@ -297,6 +297,19 @@ class Engine:
         """LAUNCH_PER_PASS / LAUNCH_PER_SNP / LAUNCH_PER_SCHEDULE -- tsamd_set_launch_mode"""
         self._check(self.h.tsamd_set_launch_mode(self.ctx, int(mode)))
 
+    def recoveries(self):
+        """times a resident launch found its workgroups not all resident and the schedule was replayed launch per pass"""
+        v = C.c_uint32(0)
+        self._check(self.h.tsamd_recoveries(self.ctx, C.byref(v)))
+        return v.value
+
+    def debug_occupy(self, workgroups, milliseconds):
+        """test aid: hold `workgroups` compute units for `milliseconds` with a kernel on a second stream"""
+        self._check(self.h.tsamd_debug_occupy(self.ctx, int(workgroups), int(milliseconds)))
+
+    def last_error(self):
+        return self.h.tsamd_last_error(self.ctx).decode()
+
     def mem_info(self):
         f, t = C.c_uint64(0), C.c_uint64(0)
         self._check(self.h.tsamd_mem_info(self.ctx, C.byref(f), C.byref(t)))

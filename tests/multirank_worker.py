@@ -30,7 +30,10 @@ def main():
         over["max_inner"] = int(os.environ["TS_MAX_INNER"])
     if os.environ.get("TS_DELAY_RANK") == str(rank):  # this rank stalls between its flag wait and its row reads
         os.environ["TSAMD_TEST_XCHG_DELAY_US"] = os.environ.get("TS_DELAY_US", "200")
-    eng = ts.Engine(n, l, k, device=device, rank=rank, world=world, flags=int(os.environ.get("TS_FLAGS", "0")), **over)
+    flags = int(os.environ.get("TS_FLAGS", "0"))
+    if any(v.startswith("TSAMD_TEST_") for v in os.environ):
+        flags |= ts.FLAG_TEST_HOOKS           # the library honours its test hooks only when asked to
+    eng = ts.Engine(n, l, k, device=device, rank=rank, world=world, flags=flags, **over)
     b, c = eng.shard_begin, eng.shard_count
     eng.upload_bed(payload)
     eng.set_gamma(gamma[b:b + c])

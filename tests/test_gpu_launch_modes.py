@@ -3,7 +3,10 @@ first pass + one resident kernel per SNP (ts_resident), one kernel per schedule 
 stay in registers from the first SNP to the last, the gamma step reads and writes gamma only).  Every mode
 is compared with the CPU oracle (rel 1e-9, pass counts and c_n exact), the modes with each other (they
 differ by the order in which the workgroups' partial rows are added: rel 1e-11), and each mode must give
-the same BITS however the schedule is cut into calls and whichever mode ran before it.
+the same BITS however the schedule is cut into calls and whichever mode ran before it.  K = 1 ... 32: the
+resident kernels hold pairs of individuals per item at K <= 8 and single individuals above, exchange rows of
+2K values over one, two or four waves, and (ts_schedule) defer the exchange of a SNP's last pass into the
+next SNP's first one unless one of the next two SNPs revisits the location -- LOCS has every such pattern.
 """
 import numpy as np
 import pytest
@@ -36,7 +39,9 @@ def state(eng):
 
 
 @pytest.mark.parametrize("n,k,max_inner", [(1003, 4, 10), (40_000, 8, 10), (40_000, 5, 3), (70_000, 8, 1), (200_000, 3, 10),
-                                           (64, 1, 10), (5, 2, 10)])
+                                           (64, 1, 10), (5, 2, 10), (40_000, 8, 2), (30_000, 9, 10), (50_000, 12, 10),
+                                           (60_000, 16, 10), (45_000, 20, 10), (20_000, 32, 10), (9_000, 17, 3), (70_000, 24, 2),
+                                           (33_000, 25, 10), (700, 13, 10), (150_000, 10, 10), (80_000, 14, 10)])
 def test_every_mode_matches_the_oracle_and_the_others(ts, n, k, max_inner):
     l = 12
     outs = {}
@@ -115,18 +120,62 @@ def test_switching_modes_in_the_middle_of_a_run(ts):
 
 
 def test_modes_a_context_does_not_qualify_for(ts):
-    with ts.Engine(2000, 4, 12) as eng:            # K above 8: the weights do not fit the register file
+    with ts.Engine(2000, 4, 40) as eng:            # K above 32: the run-time-K fallback kernels, one launch per pass
         assert eng.launch_info()["kernels_per_snp"] == eng.cfg.max_inner
         for mode in (ts.LAUNCH_PER_SNP, ts.LAUNCH_PER_SCHEDULE):
             with pytest.raises(ts.TsamdError):
                 eng.set_launch_mode(mode)
         eng.set_launch_mode(ts.LAUNCH_PER_PASS)
+    with ts.Engine(400_000, 4, 20) as eng:         # K = 20 holds 5 individuals per thread: 327 680 per GPU
+        assert eng.launch_info()["kernels_per_snp"] == eng.cfg.max_inner
+        with pytest.raises(ts.TsamdError):
+            eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+    with ts.Engine(327_680, 4, 20) as eng:
+        assert eng.launch_info()["kernels_per_snp"] == 0
     with ts.Engine(2000, 4, 4, nodekappa=0.7) as eng:   # the whole-schedule kernel has the reference's default exponent built in
         assert eng.launch_info()["kernels_per_snp"] == 2
         with pytest.raises(ts.TsamdError):
             eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
         with pytest.raises(ts.TsamdError):
             eng.set_launch_mode(7)
+
+
+@pytest.mark.parametrize("k", [8, 12, 20])
+def test_deferred_last_exchange_patterns(ts, k):
+    """ts_schedule parks the row of a SNP's last pass (under the pass cap) for the next SNP's first exchange unless the
+    next or the next-but-one SNP is at the same location, the launch ends, or the SNP stopped early.  Every such
+    neighbourhood, with a pass cap of 2 (the deferred pass directly follows the first) and of 10, with converging SNPs
+    mixed in, cut into launches at every position: against the oracle and bitwise against uncut."""
+    n, l = 30_000, 6
+    locs = np.array([0, 1, 2, 0, 0, 3, 4, 3, 5, 5, 5, 1, 2, 1, 0, 4, 4, 2, 3, 3, 1, 5, 0, 2], dtype=np.uint32)
+    for max_inner, thresh in ((10, None), (2, None), (10, 6.0), (3, 2.0)):
+        over = {} if thresh is None else {"conv_thresh": thresh}
+        eng, orc, payload, g = make(ts, n, l, k, 400 + k, max_inner=max_inner, **over)
+        if thresh is not None:
+            orc.close()
+            orc = op.Oracle(n, l, k, online_iterations=max_inner, meanchangethresh=thresh)
+            orc.load_bed_payload(payload)
+            orc.set_gamma(g)
+        with eng:
+            assert eng.launch_info()["kernels_per_snp"] == 0
+            eng.run_schedule(locs)
+            eng.synchronize()
+            its = [orc.snp_update(int(x)) for x in locs]
+            if thresh is not None:
+                assert len(set(its)) >= 2, its
+            assert eng.total_passes() == sum(its)
+            assert_state_close(eng, orc, 1e-9, f"max_inner {max_inner} thresh {thresh}")
+            whole = state(eng)
+        for cut in (1, 2, 5, 11, 23):
+            eng2 = ts.Engine(n, l, k, max_inner=max_inner, **over)
+            with eng2:
+                eng2.upload_bed(payload)
+                eng2.set_gamma(g)
+                eng2.run_schedule(locs[:cut])
+                eng2.run_schedule(locs[cut:])
+                eng2.synchronize()
+                for a, b in zip(state(eng2), whole):
+                    assert np.array_equal(a, b), (max_inner, thresh, cut)
 
 
 def test_other_learning_rate_exponent_runs_per_snp_and_matches(ts):

@@ -123,9 +123,12 @@ def test_p2p_small_pass_caps(tmp_path, world, max_inner):
 
 @pytest.mark.parametrize("world,n,k,thresh,max_inner", [(2, 40_000, 8, None, None), (4, 70_000, 5, None, None),
                                                         (2, 60_000, 8, 8.0, None), (3, 50_000, 3, None, 3),
-                                                        (8, 70_000, 8, None, None), (2, 300_000, 8, None, None)])
+                                                        (8, 70_000, 8, None, None), (2, 300_000, 8, None, None),
+                                                        (2, 40_000, 12, None, None), (2, 60_000, 20, 30.0, None),
+                                                        (4, 90_000, 16, None, None), (3, 50_000, 32, None, 4),
+                                                        (8, 125_000, 20, None, None)])
 def test_sharded_schedule_kernel_matches_oracle(tmp_path, world, n, k, thresh, max_inner):
-    """Shards of at least 8 workgroups, K <= 8: every rank runs the whole schedule as ONE launch (ts_schedule) whose
+    """Shards of at least 8 workgroups, K <= 32: every rank runs the whole schedule as ONE launch (ts_schedule) whose
     in-launch exchange spans the ranks -- group sums stored into every rank's buffer, each rank polls its own copy.
     Against the oracle; replicated state bitwise equal on all ranks; with SNPs that stop after differing pass counts and
     with a pass cap of 3.  The same shards with one launch per pass (TS_LAUNCH_MODE=0) must agree to rounding."""

@@ -44,15 +44,30 @@ def _held_sets(y, seed, per_loc):
 CALLS = [([3, 3, 5, 1, 6, 1, 2, 0, 7, 7, 4, 5, 3, 6, 2, 1, 0], 0), ([5], 1), ([6, 1, 6, 0], 0)]
 
 
-@pytest.mark.parametrize("n,k,thresh", [(300_000, 8, None), (1_000_000, 8, None), (125_000, 20, None),
+def _launch_modes(ts, eng):
+    """every launch mode the context qualifies for (the default one first)"""
+    modes = [None]
+    for m in (ts.LAUNCH_PER_SNP, ts.LAUNCH_PER_PASS):
+        try:
+            eng.set_launch_mode(m)
+            modes.append(m)
+        except ts.TsamdError:
+            pass
+    return modes
+
+
+@pytest.mark.parametrize("n,k,thresh", [(100_000, 8, None), (300_000, 8, None), (1_000_000, 8, None), (125_000, 20, None),
                                         (1_000_000, 20, None), (300_000, 8, 20.0), (1_000_000, 20, 40.0),
-                                        (600_000, 8, None), (600_000, 8, 30.0), (600_000, 8, 40.0)])
+                                        (600_000, 8, None), (600_000, 8, 30.0), (600_000, 8, 40.0), (1_000_000, 8, 30.0),
+                                        (500_000, 16, None), (250_000, 12, 30.0)])
 def test_benchmarked_geometry_matches_oracle(ts, n, k, thresh):
-    """run_schedule (hipGraph replay) and eager snp_update calls at N up to 1M, K = 8 and 20;
-    `thresh` raises meanchangethresh so that SNPs stop after differing numbers of passes.  From
-    N = 512K at K <= 8 the plain passes of a SNP run as ONE resident launch (ts_resident: weights in
-    registers, in-launch exchange of the partial rows); N = 600K puts six items in each of its threads
-    and, with a threshold, ends its pass loop after 1 ... 10 passes."""
+    """Every kernel sequence the library can run at the benchmarked sizes, against the oracle: for each
+    launch mode the context qualifies for -- one launch per schedule (ts_schedule, the default where the
+    shard's weights fit the register file), per SNP (first pass + ts_resident: 6 items per thread at
+    N = 600K, 8 at N = 1M) and per pass (ts_pass<K,true,256,1> + ts_pass<K,false,512,2>, hipGraph
+    replay) -- run_schedule calls and eager snp_update calls.  `thresh` raises meanchangethresh so that
+    SNPs stop after differing numbers of passes (1 ... 10).  N = 100K, K = 8 is BASELINE config 3's
+    shape, N = 1M those of configs 4 and 5 on one GPU."""
     l = 8
     y, _, _ = psd_genotypes(n, l, k, 4000 + k, 0.02)
     payload = pack_bed(y)
@@ -75,29 +90,114 @@ def test_benchmarked_geometry_matches_oracle(ts, n, k, thresh):
     else:
         assert len(set(its)) >= 3, f"pass counts do not vary: {sorted(set(its))}"
 
-    res = {}
-    for mode in ("graph", "eager"):
-        with ts.Engine(n, l, k, flags=0 if mode == "graph" else ts.FLAG_NO_GRAPH, **over_d) as eng:
-            eng.upload_bed(payload)
-            eng.set_gamma(g)
-            for loc, ids in held.items():
-                eng.set_heldout(loc, ids)
-            if mode == "graph":
-                for locs, hol in CALLS:
-                    eng.run_schedule(np.array(locs, dtype=np.uint32), hol)
-                eng.synchronize()
-            else:
-                its_d = [eng.snp_update(loc, hol) for locs, hol in CALLS for loc in locs]
-                assert its_d == its
-            assert eng.total_passes() == sum(its)
-            assert np.array_equal(eng.pass_histogram(), np.bincount(its, minlength=128).astype(np.uint64))
-            lam_d, gam_d, cnt_d = eng.get_lambda(), eng.get_gamma(), eng.get_counts()
-        assert np.array_equal(cnt_d, cnt_o), mode + " c_n"
-        e_lam, e_gam = rel_err(lam_d, lam_o), rel_err(gam_d, gam_o)
-        assert e_lam < 1e-9 and e_gam < 1e-9, (mode, e_lam, e_gam)
-        res[mode] = (lam_d, gam_d)
-    # and graph replay == eager launches, bit for bit
-    assert np.array_equal(res["graph"][0], res["eager"][0]) and np.array_equal(res["graph"][1], res["eager"][1])
+    with ts.Engine(n, l, k) as probe:
+        launch_modes = _launch_modes(ts, probe)
+    if k <= 8 and n <= 1_000_000:
+        assert len(launch_modes) == 3, "K <= 8 at these sizes qualifies for every launch mode"
+    per_mode = {}
+    for launch in launch_modes:
+        res = {}
+        for mode in ("graph", "eager"):
+            with ts.Engine(n, l, k, flags=0 if mode == "graph" else ts.FLAG_NO_GRAPH, **over_d) as eng:
+                if launch is not None:
+                    eng.set_launch_mode(launch)
+                eng.upload_bed(payload)
+                eng.set_gamma(g)
+                for loc, ids in held.items():
+                    eng.set_heldout(loc, ids)
+                if mode == "graph":
+                    for locs, hol in CALLS:
+                        eng.run_schedule(np.array(locs, dtype=np.uint32), hol)
+                    eng.synchronize()
+                else:
+                    its_d = [eng.snp_update(loc, hol) for locs, hol in CALLS for loc in locs]
+                    assert its_d == its, (launch, mode)
+                assert eng.total_passes() == sum(its)
+                assert np.array_equal(eng.pass_histogram(), np.bincount(its, minlength=128).astype(np.uint64))
+                lam_d, gam_d, cnt_d = eng.get_lambda(), eng.get_gamma(), eng.get_counts()
+            assert np.array_equal(cnt_d, cnt_o), (launch, mode, "c_n")
+            e_lam, e_gam = rel_err(lam_d, lam_o), rel_err(gam_d, gam_o)
+            assert e_lam < 1e-9 and e_gam < 1e-9, (launch, mode, e_lam, e_gam)
+            res[mode] = (lam_d, gam_d)
+        # within a launch mode: one call per schedule == one call per update, bit for bit
+        assert np.array_equal(res["graph"][0], res["eager"][0]) and np.array_equal(res["graph"][1], res["eager"][1]), launch
+        per_mode[launch] = res["graph"]
+    # the modes differ by the order in which the workgroups' partial rows are added
+    for launch, got in per_mode.items():
+        assert rel_err(got[0], per_mode[None][0]) < 1e-10 and rel_err(got[1], per_mode[None][1]) < 1e-10, launch
+
+
+def test_config3_full_size_properties(ts):
+    """BASELINE config 3 at its full size -- N = 100 000 individuals x L = 500 000 SNPs, K = 8, the whole
+    2-bit matrix (12.5 GB) resident -- where the oracle cannot follow: 3 000 updates over random locations,
+    then size-independent properties of the path:
+      * sum_{k,t} (lambda[loc][k][t] - eta_t) = 2 x (observed genotypes at loc) for every visited location
+        (phi_mom and phi_dad each sum to 1 over k, src/snpsamplinge.cc:742-759), untouched locations keep eta;
+      * c_n = the number of updates in which individual n was observed (update_rho_indiv, :705-719);
+      * every gamma row sum follows S <- (1 - rho) S + rho (K alpha + 2 L), replayed
+        on the host from c_n alone;
+    and the oracle itself on 8 of the matrix' own columns: the same 24 updates from the same state."""
+    n, l, k = 100_000, 500_000, 8
+    rng = np.random.default_rng(303)
+    theta = rng.dirichlet(np.full(k, 0.2), size=n)
+    g0 = rng.gamma(100.0, 0.01, size=(n, k))
+    with ts.Engine(n, l, k) as eng:
+        assert eng.launch_info()["kernels_per_snp"] == 0   # ts_schedule
+        chunk = 1 << 16
+        brng = np.random.default_rng(304)
+        for l0 in range(0, l, chunk):
+            eng.synth_genotypes(theta, brng.uniform(0.05, 0.95, size=(min(chunk, l - l0), k)), first_loc=l0, seed=9,
+                                missing_rate=0.01)
+        eng.set_gamma(g0)
+        locs = rng.integers(0, l, size=3000).astype(np.uint32)
+        eng.run_schedule(locs)
+        eng.synchronize()
+        assert eng.total_passes() == 10 * len(locs)
+        gam, cn = eng.get_gamma(), eng.get_counts()
+        # lambda of visited / unvisited locations
+        visited = np.unique(locs)
+        for loc in visited[:: max(1, len(visited) // 40)]:
+            cnt = eng.genotype_counts(int(loc), 1)
+            observed = int(cnt[0] + cnt[2] + cnt[3])
+            lam = eng.get_lambda(int(loc), 1)[0]
+            assert abs(float(np.sum(lam - 1.0)) - 2.0 * observed) < 1e-7 * observed, loc
+        unvisited = np.setdiff1d(np.arange(0, l, 9973), visited)[:20]
+        for loc in unvisited:
+            assert np.array_equal(eng.get_lambda(int(loc), 1)[0], np.ones((k, 2)))
+        # c_n: observed updates per individual -- all but the last SNP's step have been applied (deferred)
+        want_cn = np.zeros(n, dtype=np.uint32)
+        for loc in locs[:-1]:
+            bits = np.unpackbits(eng.download_bed(int(loc)), bitorder="little")[: 2 * n].reshape(n, 2)
+            want_cn += ~((bits[:, 0] == 1) & (bits[:, 1] == 0))        # PLINK 01 (low bit first) = missing
+        assert np.array_equal(cn, want_cn)
+        # gamma row sums from c_n alone: rho_j = (tau0 + j)^-kappa for the j-th observed update
+        target = k * (1.0 / k) + 2.0 * l
+        s = g0.sum(axis=1)
+        for j in range(int(cn.max())):
+            rho = (2.0 + j) ** -0.5
+            s = np.where(cn > j, (1.0 - rho) * s + rho * target, s)
+        assert rel_err(gam.sum(axis=1), s) < 1e-10
+        # the oracle on 8 of these columns, same state, same updates (gamma_scale = L like the engine)
+        ls = 8
+        sample = np.stack([eng.download_bed(j) for j in range(ls)])
+        orc = op.Oracle(n, ls, k, nthreads=usable_cores(), gamma_scale=float(l))
+        orc.load_bed_payload(sample)
+        orc.set_gamma(g0)
+        seq = [0, 3, 3, 1, 7, 5, 2, 6, 4, 0, 1, 1, 2, 7, 3, 5, 6, 4, 0, 2, 5, 7, 1, 3]
+        its = [orc.snp_update(j) for j in seq]
+        for j in range(ls):
+            eng.set_lambda(j, np.ones((k, 2)))
+        eng.set_gamma(g0)
+        eng.set_counts(np.zeros(n, dtype=np.uint32))
+        eng.clear_pending()
+        p0 = eng.total_passes()
+        eng.run_schedule(np.array(seq, dtype=np.uint32))
+        eng.synchronize()
+        assert eng.total_passes() - p0 == sum(its)
+        assert rel_err(eng.get_lambda(0, ls), orc.lambda_()) < 1e-9
+        assert rel_err(eng.get_gamma(), orc.gamma()) < 1e-9
+        assert np.array_equal(eng.get_counts(), orc.c_indiv())
+        orc.close()
 
 
 @pytest.mark.parametrize("k,block", [(1, 256), (3, 512), (8, 256), (8, 512), (8, 1024), (12, 512), (16, 512), (17, 256),
