@@ -41,9 +41,9 @@ SELFTEST_TOL = 1e-9    # exchange self-test: lambda / gamma vs the CPU oracle af
 def resident_geometry(k):
     """(individuals per item, items per thread, items whose gamma stays in LDS) of the resident kernels --
     mirrors resident_vec / resident_items / sched_lds_items in csrc/tsamd_resident_kernels.h"""
-    vec = 2 if k <= 8 else 1
-    items = 8 if k <= 8 else 128 // k if k <= 16 else 112 // k if k <= 24 else 3
-    small = 1024 + 18 * 2 * k * 8
+    vec = 1
+    items = 16 if k <= 8 else 128 // k if k <= 16 else 112 // k if k <= 24 else 3
+    small = 1536 + 18 * 2 * k * 8
     lds = min(items, (160 * 1024 - small) // ((k * 8 + 4) * vec * 256))
     return vec, items, lds
 

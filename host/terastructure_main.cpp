@@ -191,6 +191,15 @@ void run_all(Run &r, const uint32_t *locs, uint32_t n, int hol_mode) {
       r.ctx = c;
       die(r, "tsamd_synchronize");
     }
+  // a resident launch that found compute units of its GPU taken was replayed one launch per pass (include/tsamd.h,
+  // tsamd_set_launch_mode): the run goes on, the log says so once per event
+  static uint32_t seen = 0;
+  uint32_t now = 0;
+  if (tsamd_recoveries(r.ctx, &now) == 0 && now != seen) {
+    seen = now;
+    fprintf(stderr, "%s\n", tsamd_last_error(r.ctx));
+    r.lerr("%s", tsamd_last_error(r.ctx));
+  }
 }
 
 void set_gamma_all(Run &r, const std::vector<double> &g) {

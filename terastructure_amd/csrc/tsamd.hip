@@ -719,14 +719,10 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
     const int cus = hipGetDeviceProperties(&prop, c->dev) == hipSuccess ? prop.multiProcessorCount : 0;
     c->sched_grid = c->grid;
     c->sched_chunk = p.chunk;
-    bool fits;
-    if (cfg->k <= 8u)  // (items are pairs: the plain pass' own geometry -- TSAMD_GRID / TSAMD_BLOCK apply)
-      fits = !c->wide && p.chunk <= (uint32_t)(resident_items((int)cfg->k) * kResidentBlock) && (int)c->grid <= cus &&
-             c->grid <= (uint32_t)(kResGroups * kResMembers);
-    else
-      fits = !c->wide && cus > 0 && env_u32("TSAMD_GRID", 0) == 0u &&
-             resident_geometry(cfg->k, c->npad, std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)cus), &c->sched_grid,
-                               &c->sched_chunk);
+    // (TSAMD_GRID / TSAMD_BLOCK shape the launch-per-pass kernels: a context they are set for runs those)
+    const bool fits = !c->wide && cus > 0 && env_u32("TSAMD_GRID", 0) == 0u &&
+                      resident_geometry(cfg->k, c->npad, std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)cus), &c->sched_grid,
+                                        &c->sched_chunk);
     c->resident = fits && !c->split && cfg->world == 1 && cfg->max_inner >= 2 && cfg->max_inner <= 200 &&
                   env_u32("TSAMD_RESIDENT", 1) != 0u && kResidentBlocksPerCu[cfg->k]() >= 1;
     // ... and then, with the reference's default learning-rate exponent (the kernel carries no pow()), the whole

@@ -4,11 +4,11 @@
 //   ts_schedule<K,PARTIAL,WR> a WHOLE schedule in one launch: gamma steps, passes, epilogues (mode "per schedule")
 //
 // 256 workgroups of 256 threads, one per compute unit, ONE wave per SIMD: a thread owns the whole 512-entry register
-// file.  Per K a thread holds resident_items(K) items of resident_vec(K) individuals:
-//   K <= 8      8 items x 2 individuals (16-byte row accesses)                     -> 1 048 576 individuals per GPU
-//   K = 9..16   floor(128 / K) items x 1 individual (14 at K = 9 ... 8 at K = 16)  -> 917 504 ... 524 288
-//   K = 17..24  floor(112 / K) items x 1 individual (6 at K = 17 ... 4 at K = 24)  -> 393 216 ... 262 144
-//   K = 25..32  3 items x 1 individual                                             -> 196 608
+// file.  Per K a thread holds resident_items(K) items of one individual each:
+//   K <= 8      16 items                                         -> 1 048 576 individuals per GPU
+//   K = 9..16   floor(128 / K) items (14 at K = 9 ... 8 at K = 16)  -> 917 504 ... 524 288
+//   K = 17..24  floor(112 / K) items (6 at K = 17 ... 4 at K = 24)  -> 393 216 ... 262 144
+//   K = 25..32  3 items                                           -> 196 608
 // i.e. at most 128 doubles = 256 registers of weights per thread (the AGPR half of the file) next to the gamma
 // step's K-sized temporaries (which is why the budget shrinks as K grows).  Between passes the workgroups all-reduce their partial rows INSIDE the launch
 // (ResXchg below).  Restated reference code: as ts_pass (tsamd_kernels.h) -- PhiRunnerE::process / update_phimom /
@@ -22,16 +22,12 @@ namespace tsamd {
 // ---- geometry per K ---------------------------------------------------------------------------------------------
 constexpr int kResidentMaxK = 32;
 constexpr int kResidentBlock = 256;
-#ifdef TSAMD_RES_VEC  // (experiments, UNIT=all tools/variant.sh: the geometry of every K <= 8)
+#ifdef TSAMD_RES_VEC  // (experiments, UNIT=all tools/variant.sh: 2 = pairs of individuals per item at K <= 8, round 2's geometry)
 constexpr int resident_vec(int k) { return k <= 8 ? TSAMD_RES_VEC : 1; }
 #else
-constexpr int resident_vec(int k) { return k <= 8 ? 2 : 1; }
+constexpr int resident_vec(int) { return 1; }
 #endif
-#ifdef TSAMD_RES_ITEMS
-constexpr int resident_items(int k) { return k <= 8 ? TSAMD_RES_ITEMS : k <= 16 ? 128 / k : k <= 24 ? 112 / k : 3; }
-#else
-constexpr int resident_items(int k) { return k <= 8 ? 8 : k <= 16 ? 128 / k : k <= 24 ? 112 / k : 3; }
-#endif
+constexpr int resident_items(int k) { return k <= 8 ? 16 / resident_vec(k) : k <= 16 ? 128 / k : k <= 24 ? 112 / k : 3; }
 // individuals a workgroup can hold
 constexpr int resident_capacity(int k) { return resident_items(k) * resident_vec(k) * kResidentBlock; }
 
@@ -217,10 +213,28 @@ struct ResCodes {
   static constexpr uint32_t kMissing = VEC == 2 ? 0x5u : 0x1u;  // PLINK 01 for every individual of the item
 };
 
+#ifdef TSAMD_EXP_TABLE  // (experiment, tools/variant.sh: the exponentials of the gamma step through a 2^(j/64) table in LDS)
+#define TSAMD_EXPD(x, tab) exp_nonpos_tab((x), (tab))
+#else
+#define TSAMD_EXPD(x, tab) exp_nonpos(x)
+#endif
+// gamma_to_w (tsamd_kernels.h) with the exponential above
+template <int KT>
+__device__ __forceinline__ void gamma_to_w_res(const double (&g)[KT], double (&w)[KT], const double *tab) {
+  double z[KT], a[KT];
+  double amax = -1.0e300;
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    exp_digamma_split(g[k], z[k], a[k]);
+    amax = fmax(amax, a[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < KT; ++k) w[k] = z[k] * TSAMD_EXPD(a[k] - amax, tab);
+}
 // w = exp(psi(g)) up to a per-individual factor, like gamma_to_w, holding K instead of 2K temporaries across the
 // maximum (z = g + 10 is formed again instead of kept): the large-K instantiations live on their registers
 template <int KT>
-__device__ __forceinline__ void gamma_to_w_lean(const double (&g)[KT], double (&w)[KT]) {
+__device__ __forceinline__ void gamma_to_w_lean(const double (&g)[KT], double (&w)[KT], const double *tab) {
   double a[KT];
   double amax = -1.0e300;
 #pragma unroll
@@ -233,13 +247,14 @@ __device__ __forceinline__ void gamma_to_w_lean(const double (&g)[KT], double (&
   for (int k = 0; k < KT; ++k) {
     double gk = g[k];
     asm volatile("" : "+v"(gk));  // (opaque: otherwise the z of the first loop is kept alive instead)
-    w[k] = (gk + 10.0) * exp_nonpos(a[k] - amax);
+    w[k] = (gk + 10.0) * TSAMD_EXPD(a[k] - amax, tab);
   }
 }
 
 // The sweep of one item: both parents' normalisers and the 2K accumulations per individual
 // (update_phimom / update_phidad / update_lambda_t in the linear domain, tsamd_device.h).  BS: exp(Elogbeta) in
-// scalar registers (b0 / b1, K <= 8); otherwise read as (b[k][0], b[k][1]) pairs from LDS at every use.
+// registers for the whole sweep (b0 / b1: scalar registers at K <= 8, vector registers up to K = 24); otherwise
+// read as (b[k][0], b[k][1]) pairs from LDS at every use.
 template <int KT, int VEC, bool BS>
 __device__ __forceinline__ void res_consume(const typename Lanes<VEC>::T (&wv)[KT], uint32_t code, const double (&b0)[BS ? KT : 1],
                                             const double (&b1)[BS ? KT : 1], const double2 *s_b, double (&acc0)[KT], double (&acc1)[KT]) {
@@ -250,19 +265,36 @@ __device__ __forceinline__ void res_consume(const typename Lanes<VEC>::T (&wv)[K
     bool ok;
     code_weights((code >> (2 * v)) & 3u, mom, dad, ok);
     double s0 = 0.0, s1 = 0.0;
+#ifdef TSAMD_TREE_SUM  // (experiment: the normalisers as two half-length chains)
+    double t0 = 0.0, t1 = 0.0;
+#endif
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       double wk;
       if constexpr (VEC == 2) wk = v ? wv[k].y : wv[k].x; else wk = wv[k];
+      double bx, by;
       if constexpr (BS) {
-        s0 = fma(wk, b0[k], s0);
-        s1 = fma(wk, b1[k], s1);
+        bx = b0[k];
+        by = b1[k];
       } else {
         const double2 b = s_b[k];
-        s0 = fma(wk, b.x, s0);
-        s1 = fma(wk, b.y, s1);
+        bx = b.x;
+        by = b.y;
       }
+#ifdef TSAMD_TREE_SUM
+      if (k & 1) {
+        t0 = fma(wk, bx, t0);
+        t1 = fma(wk, by, t1);
+        continue;
+      }
+#endif
+      s0 = fma(wk, bx, s0);
+      s1 = fma(wk, by, s1);
     }
+#ifdef TSAMD_TREE_SUM
+    s0 += t0;
+    s1 += t1;
+#endif
     c0[v] = mom * fast_rcp(s0);
     c1[v] = dad * fast_rcp(s1);
   }
@@ -310,7 +342,7 @@ template <int KT>
 __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partials_a, double *w_a, uint32_t npad_a, uint32_t chunk_a,
                                                       uint32_t par_arg, uint32_t nrows_hint, ResXchg *xb, uint32_t serial, const DevParams p) {
   constexpr int BLOCK = 256, kWaves = BLOCK / 64, VEC = resident_vec(KT), kItems = resident_items(KT);
-  constexpr bool BS = KT <= 8;
+  constexpr bool BS = KT <= 24, BSC = KT <= 8;  // exp(Elogbeta) of a pass in registers / in scalar registers
   using LN = Lanes<VEC>;
   using WT = typename LN::T;
   using RC = ResCodes<VEC>;
@@ -387,9 +419,12 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
     eb_used = s_eb[tid < J ? tid : 0u];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-      if constexpr (BS) {
+      if constexpr (BSC) {
         b0[k] = uniform_f64(s_eb[2 * k]);
         b1[k] = uniform_f64(s_eb[2 * k + 1]);
+      } else if constexpr (BS) {
+        b0[k] = s_eb[2 * k];
+        b1[k] = s_eb[2 * k + 1];
       }
       acc0[k] = acc1[k] = 0.0;
     }
@@ -508,7 +543,7 @@ constexpr int sched_lds_items(int k, int items, int vec) {
 #ifdef TSAMD_SCHED_LDS_ITEMS  // (experiments, tools/variant.sh)
   return TSAMD_SCHED_LDS_ITEMS < items ? TSAMD_SCHED_LDS_ITEMS : items;
 #else
-  const int small = 1024 + 18 * 2 * k * 8;  // the K x 2 arrays below
+  const int small = 1536 + 18 * 2 * k * 8;  // the K x 2 arrays below (and the experiment's exponential table)
   const int per_item = (k * 8 + 4) * vec * 256, n = (160 * 1024 - small) / per_item;
   return n < items ? n : items;
 #endif
@@ -523,7 +558,7 @@ template <int KT, bool PARTIAL, int WR>
 __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
                                                       const uint32_t *sched, uint32_t n_sched, ResXchg *xb, uint32_t serial, const DevParams p) {
   constexpr int BLOCK = 256, kWaves = BLOCK / 64, VEC = resident_vec(KT), kItems = resident_items(KT);
-  constexpr bool BS = KT <= 8;
+  constexpr bool BS = KT <= 24, BSC = KT <= 8;  // exp(Elogbeta) of a pass in registers / in scalar registers
   using LN = Lanes<VEC>;
   using WT = typename LN::T;
   using CT = typename LN::C;
@@ -536,6 +571,11 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   __shared__ double s_drow[J], s_dlam[J], s_dolam[J], s_doeb[J], s_ddiff[J];  // the deferred last pass of the previous SNP
   __shared__ double s_red[kWaves * J];
   __shared__ int s_alive[4];
+#ifdef TSAMD_EXP_TABLE
+  __shared__ double s_exp2[64];
+#else
+  double *const s_exp2 = nullptr;
+#endif
   // gamma (and c_n) of kLds of a thread's items stay in LDS for the whole launch, spread evenly over the items; the
   // gamma step streams the others from memory, one streamed item ahead.  Memory sees them again when the launch ends.
   constexpr int kLds = sched_lds_items(KT, kItems, VEC);
@@ -573,6 +613,9 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     return;
   }
   if (tid < 4) s_alive[tid] = 1;
+#ifdef TSAMD_EXP_TABLE
+  if (tid < 64) s_exp2[tid] = kExp2Tab[tid];
+#endif
   __syncthreads();
   uint32_t xcount = 1u;  // exchanges of this launch
   // the entry exchange: empty rows, nothing modified yet.  All workgroups resident?
@@ -603,12 +646,15 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
 #pragma unroll
     for (int k = 0; k < KT; ++k) buf[t][k] = wv[k];
   };
-  // the 2-bit codes of a column for this thread's items, packed into one register (an item the thread does not own: missing)
-  auto load_codes = [&](uint32_t loc_) -> uint32_t {
+  // the 2-bit codes of a column for this thread's items, packed into one register (an item the thread does not own:
+  // missing).  In two steps, so that the words of the NEXT SNP's column can be requested a SNP ahead and packed when
+  // they are needed.
+  auto load_words = [&](uint32_t loc_, uint32_t (&word)[kItems]) {
     const uint32_t *col = reinterpret_cast<const uint32_t *>(p.bed + (size_t)loc_ * p.colstride);
-    uint32_t word[kItems];
 #pragma unroll
     for (int t = 0; t < kItems; ++t) word[t] = col[item_or_last((uint32_t)t) / RC::kItemsPerWord];
+  };
+  auto pack_codes = [&](const uint32_t (&word)[kItems]) -> uint32_t {
     uint32_t out = 0u;
 #pragma unroll
     for (int t = 0; t < kItems; ++t) {
@@ -617,6 +663,11 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       out |= c << (RC::kCodeBits * (uint32_t)t);
     }
     return out;
+  };
+  auto load_codes = [&](uint32_t loc_) -> uint32_t {
+    uint32_t word[kItems];
+    load_words(loc_, word);
+    return pack_codes(word);
   };
   // the previous call's last SNP: its gamma step may be pending (column bits, exp(Elogbeta) of its last
   // pass), and its final values serve a first SNP at the same location
@@ -657,7 +708,8 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   double lam_old = 0.0, eb_used = 0.0;
   double b0[BS ? KT : 1], b1[BS ? KT : 1], acc0[KT], acc1[KT];
   bool complete = false;
-  uint32_t codes = 0u;
+  uint32_t codes = load_codes(sched[0] & 0x7fffffffu);  // (every later SNP's column is requested while its predecessor runs)
+  uint32_t nword[kItems];
   auto begin_pass = [&]() {
     fresh();
     iters += 1u;
@@ -665,9 +717,12 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     eb_used = s_eb[tid < J ? tid : 0u];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-      if constexpr (BS) {
+      if constexpr (BSC) {
         b0[k] = uniform_f64(s_eb[2 * k]);
         b1[k] = uniform_f64(s_eb[2 * k + 1]);
+      } else if constexpr (BS) {
+        b0[k] = s_eb[2 * k];
+        b1[k] = s_eb[2 * k + 1];
       }
       acc0[k] = acc1[k] = 0.0;
     }
@@ -721,6 +776,9 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     }
     const uint32_t width = deferred ? 2u : 1u;
     if (deferred && tid >= 64u && tid < 64u + J) mine = s_drow[tid - 64u];
+    // workgroup 0 publishes a SNP's final lambda / exp(Elogbeta) with plain agent-scope stores (threads < J, its first
+    // wave) and must have them out before it joins the next exchange: whoever completes that exchange may read them
+    if (blockIdx.x == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     xcount += 1u;
     const uint32_t tag = xseq0 + xcount;
     if (!res_exchange<KT, WR>(xb, p, tag, width, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial), kResWaitTicks))
@@ -739,8 +797,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
           __hip_atomic_store(&p.lam[(size_t)dloc * J + tid], s_dolam[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&p.eb[(size_t)dloc * J + tid], s_doeb[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (tid == 0) count_snp(p, ctl, diters);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) count_snp(p, ctl, diters);  // (published before this workgroup joins the next exchange: see the wait above)
       }
       deferred = false;
     }
@@ -774,7 +831,6 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       s_eb[tid] = local ? s_peb[tid] : neb;
     }
     fresh();
-    codes = load_codes(loc);
     __syncthreads();
     iters = 0u;
     TSAMD_TK(tk_head);
@@ -814,7 +870,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
           const double e = c0 * (wx[k] * sbv[2 * k]) + c1 * (wx[k] * sbv[2 * k + 1]);
           gx[k] += rho * (p.alpha + p.gamma_scale * e - gx[k]);
         }
-        if constexpr (KT <= 8) gamma_to_w<KT>(gx, wx); else gamma_to_w_lean<KT>(gx, wx);
+        if constexpr (KT <= 8) gamma_to_w_res<KT>(gx, wx, s_exp2 + zo); else gamma_to_w_lean<KT>(gx, wx, s_exp2 + zo);
         cn = ok ? cn + 1u : cn;
       };
       constexpr int kFirstStreamed = sched_next_streamed(-1, kLds, kItems);
@@ -896,6 +952,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       nlam = __hip_atomic_load(&p.lam[(size_t)(ent_n & 0x7fffffffu) * J + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       neb = __hip_atomic_load(&p.eb[(size_t)(ent_n & 0x7fffffffu) * J + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    load_words(ent_n & 0x7fffffffu, nword);  // (the next SNP's column: packed at the end of this SNP)
     while (!complete) {
       begin_pass();
       sweep();
@@ -925,7 +982,8 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       if (tid == 0) {
         count_snp(p, ctl, iters);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // published before this workgroup joins the next exchange
+      // (published before this workgroup joins the next exchange: its first wave waits for these stores when it is
+      // about to post its next row -- finish_pass -- by when they have long landed)
     }
     __syncthreads();
     if (tid < J) {
@@ -934,6 +992,8 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       s_peb[tid] = s_eb[tid];
     }
     pcodes = codes;
+    fresh();
+    codes = pack_codes(nword);
     do_gamma = hol == 0u;
     prev_valid = true;
     prev_loc = loc;

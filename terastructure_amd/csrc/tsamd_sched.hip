@@ -13,7 +13,10 @@
 namespace tsamd {
 
 static_assert(TSAMD_K <= kResidentMaxK, "ts_schedule holds the shard's weights in registers");
-constexpr bool kAlwaysPartial = (TSAMD_K) > 8;
+#ifndef TSAMD_ALWAYS_PARTIAL  // (experiment: 1 = every K runs the instantiation with the skip branches)
+#define TSAMD_ALWAYS_PARTIAL 0
+#endif
+constexpr bool kAlwaysPartial = (TSAMD_K) > 8 || TSAMD_ALWAYS_PARTIAL;
 static_assert(offsetof(ResXchg, abort_word) == 0, "sequence_aborted() reads the first word of the buffer");
 static_assert(sizeof(((Xchg *)nullptr)->res_sums) / sizeof(unsigned long long) >= 2u * 2u * kMaxRanks * kResGroups * ResLay<TSAMD_K>::GR,
               "Xchg::res_sums holds two slots x two regions of world x 8 rows");

@@ -29,14 +29,22 @@ def test_bench_json_contract():
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-3          # value = steps / time
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
-    assert "N=30000 K=8" in d["metric"]                                       # names the workload that ran
-    # one GPU, K = 8: the whole schedule is one launch of ts_schedule; the kernels of the launch-per-SNP
+    # one GPU, K = 8: the whole schedule is one launch of ts_schedule, bound by fp64 vector issue (one wave per SIMD);
+    # its memory side and the reference-dataflow equivalent are secondary objects; the kernels of the launch-per-SNP
     # sequence are timed beside it
+    assert rf["bound"] == "fp64_valu" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf and 0.0 < rf["frac"] < 1.0
+    assert "N=30000 K=8" in d["metric"]                                       # names the workload that ran
     assert "ts_schedule" in rf["kernel"] and rf["updates_per_launch"] == 60 and rf["launches_timed"] == 1
-    # (K = 8: gamma and c_n of half of the items stay in LDS)
-    assert rf["algorithmic_bytes_per_update"] > rf["moved_bytes_per_update"] == (16.0 * 30000 * 8 + 8.0 * 30000) / 2 + 30000 / 4.0
+    assert rf["flops_per_update"] > 0 and rf["flops_source"]
+    hb = rf["hbm"]
+    assert hb["bound"] == "hbm" and hb["peak"] == 8000.0 and hb["unit"] == "GB/s" and 0.0 < hb["moved_frac"] < 1.0
+    # (K = 8: gamma and c_n of 9 of a thread's 16 individuals stay in LDS)
+    assert hb["moved_bytes_per_update"] == (16.0 * 30000 * 8 + 8.0 * 30000) * 7 / 16 + 30000 / 4.0
+    eq = rf["algorithmic_bandwidth_equiv"]
+    assert eq["bytes_per_update"] > hb["moved_bytes_per_update"] and "frac" not in eq
+    assert rf["latency"]["exchanges_per_update"] > 0
+    assert "update_hbm_frac_of_peak" not in d
     assert abs(rf["per_update_us"] * rf["updates_per_launch"] - rf["avg_launch_us"]) < 0.1 * rf["avg_launch_us"]
     ps = rf["launch_per_snp"]
     assert "ts_resident" in ps["kernel"] and ps["probe_read_us"] > 0 and "tsamd_probe_stream" in ps["ceiling_note"]
@@ -47,8 +55,11 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] and cb["sample"]
     assert cb["value_1_thread"] > 0
-    pv = d["parity_vs_cpu_baseline"]                                         # GPU vs the oracle on the timed updates
+    pv = d["parity_vs_cpu_baseline"]                                         # GPU vs the oracle on the timed updates ...
     assert pv["ok"] and pv["c_n_equal"] and pv["lambda_rel_err"] < 1e-9 and pv["gamma_rel_err"] < 1e-9
+    om = pv["other_launch_modes"]                                            # ... in every launch mode the line publishes timings of
+    assert set(om) == {"launch_per_snp", "launch_per_pass"} and all(o["ok"] and o["c_n_equal"] for o in om.values())
+    assert pv["kernels_per_snp"] == 0 and om["launch_per_snp"]["kernels_per_snp"] == 2 and om["launch_per_pass"]["kernels_per_snp"] == 10
     assert sum(d["inner_passes_histogram"].values()) == 60
 
 
