@@ -1310,6 +1310,16 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   // (not on a peer-to-peer context: its kernels wait for peers the caller may not have enqueued yet)
   if (!c->p2p && c->journal.size() >= 256)
     if (int rc = settle(c)) return rc;
+  // A single update per call (tsamd_snp_update) through ts_schedule pays for loading the shard's weights and the LDS
+  // half of gamma and writing them back around ONE update; from about 4M weights per GPU on, the launch-per-SNP
+  // sequence is the faster route for such a call (N = 1M, K = 8: 7 830 against 6 860 calls/s; N = 125K, K = 20: 8 200
+  // against 9 430, tools/single_update_rate.py).  The State either sequence leaves is the other's start.
+  const bool single_route = n == 1u && c->persistent && c->can_resident && (uint64_t)c->n_local * c->cfg.k >= (4ull << 20) &&
+                            env_u32("TSAMD_SINGLE_ROUTE", 1) != 0u;
+  if (single_route) {
+    c->persistent = false;
+    c->resident = true;
+  }
   // the schedule goes up through a pinned buffer: the copy is then really asynchronous
   tsamd_ctx::Journal j{nullptr, 0, n, c->launch_serial, c->persistent ? 2 : c->resident ? 1 : 0};
   for (size_t i = 0; i < c->sched_free.size(); ++i)
@@ -1323,12 +1333,17 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
     size_t cap = 1024;
     while (cap < n) cap *= 2;
     // (portable + mapped: ts_schedule reads the entries straight from this buffer, on whichever device the context uses)
-    HIP_TRY(c, hipHostMalloc((void **)&j.ent, cap * sizeof(uint32_t), hipHostMallocPortable | hipHostMallocMapped));
+    if (hipHostMalloc((void **)&j.ent, cap * sizeof(uint32_t), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+      if (single_route) c->persistent = true;
+      return fail(c, TSAMD_ENOMEM, "hipHostMalloc of a %zu-entry schedule buffer failed", cap);
+    }
     j.cap = cap;
   }
   c->journal.push_back(j);
   for (uint32_t i = 0; i < n; ++i) j.ent[i] = locs[i] | (hol_mode ? 0x80000000u : 0u);
-  return enqueue_entries(c, j.ent, n, false);
+  const int rc = enqueue_entries(c, j.ent, n, false);
+  if (single_route) c->persistent = true;  // (c->resident stays set: it is what the mode falls back to when lowered by one)
+  return rc;
 }
 
 int tsamd_prepare(tsamd_ctx *c) {

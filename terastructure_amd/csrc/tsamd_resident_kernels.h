@@ -646,6 +646,17 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
 #pragma unroll
     for (int k = 0; k < KT; ++k) buf[t][k] = wv[k];
   };
+  // gamma and c_n of an LDS item
+  auto get_lgamma = [&](int t, WT (&gv)[KT], CT &cv) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) gv[k] = s_gam[lds_slot(t)][k][tid];
+    cv = s_cn[lds_slot(t)][tid];
+  };
+  auto put_lgamma = [&](int t, const WT (&gv)[KT], const CT &cv) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) s_gam[lds_slot(t)][k][tid] = gv[k];
+    s_cn[lds_slot(t)][tid] = cv;
+  };
   // the 2-bit codes of a column for this thread's items, packed into one register (an item the thread does not own:
   // missing).  In two steps, so that the words of the NEXT SNP's column can be requested a SNP ahead and packed when
   // they are needed.
@@ -683,6 +694,18 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   bool w_dirty = false;
   bool deferred = false;  // the previous SNP's last row waits in s_drow for this SNP's first exchange
   uint32_t dloc = 0u, diters = 0u;
+  bool pub_pending = false;  // workgroup 0: lambda of a SNP published since its first wave last waited for its stores
+  // The SNP counters (count_snp in the launch-per-pass kernels): the histogram bin is bumped by a fire-and-forget
+  // atomic, the totals run in registers of workgroup 0's thread 0 and go to memory -- and to the pinned host mirror --
+  // when the launch ends: no dependent memory round trip on the publishing workgroup's critical path per SNP.
+  unsigned long long tp_run = ctl->total_passes;
+  uint32_t last_it = ctl->last_iters;
+  auto count_snp_deferred = [&](uint32_t its) {
+    const uint32_t bin = min(its, (uint32_t)TSAMD_PASS_HIST_BINS - 1u);
+    __hip_atomic_fetch_add(&ctl->pass_hist[bin], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (result unused: no return, no wait)
+    tp_run += (unsigned long long)its;
+    last_it = its;
+  };
 #ifdef TSAMD_SCHED_RAMP
   unsigned long long ramp_mark = wall_clock64();
   uint32_t ramp_idx = 0u;
@@ -777,8 +800,13 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     const uint32_t width = deferred ? 2u : 1u;
     if (deferred && tid >= 64u && tid < 64u + J) mine = s_drow[tid - 64u];
     // workgroup 0 publishes a SNP's final lambda / exp(Elogbeta) with plain agent-scope stores (threads < J, its first
-    // wave) and must have them out before it joins the next exchange: whoever completes that exchange may read them
-    if (blockIdx.x == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // wave) and must have them out before it joins the next exchange: whoever completes that exchange may read them.
+    // A deferred SNP is published right after a first exchange; the wait stands here, a whole sweep later, where it
+    // costs nothing.
+    if (pub_pending) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pub_pending = false;
+    }
     xcount += 1u;
     const uint32_t tag = xseq0 + xcount;
     if (!res_exchange<KT, WR>(xb, p, tag, width, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial), kResWaitTicks))
@@ -797,7 +825,8 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
           __hip_atomic_store(&p.lam[(size_t)dloc * J + tid], s_dolam[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&p.eb[(size_t)dloc * J + tid], s_doeb[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (tid == 0) count_snp(p, ctl, diters);  // (published before this workgroup joins the next exchange: see the wait above)
+        if (tid == 0) count_snp_deferred(diters);
+        pub_pending = true;  // (out before this workgroup joins the next exchange: the wait above, one sweep from now)
       }
       deferred = false;
     }
@@ -884,9 +913,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         WT gv[KT];
         CT cv;
         if (is_lds(t)) {
-#pragma unroll
-          for (int k = 0; k < KT; ++k) gv[k] = s_gam[lds_slot(t)][k][tid];
-          cv = s_cn[lds_slot(t)][tid];
+          get_lgamma(t, gv, cv);
         } else {
 #pragma unroll
           for (int k = 0; k < KT; ++k) gv[k] = gs[k];
@@ -928,9 +955,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
           gamma_one(gv, wcur, pcode, cv);
         }
         if (is_lds(t)) {
-#pragma unroll
-          for (int k = 0; k < KT; ++k) s_gam[lds_slot(t)][k][tid] = gv[k];
-          s_cn[lds_slot(t)][tid] = cv;
+          put_lgamma(t, gv, cv);
         } else if (mine) {
 #pragma unroll
           for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = gv[k];
@@ -979,11 +1004,10 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         __hip_atomic_store(&p.lam[(size_t)loc * J + tid], s_lam[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&p.eb[(size_t)loc * J + tid], s_eb[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (tid == 0) {
-        count_snp(p, ctl, iters);
-      }
-      // (published before this workgroup joins the next exchange: its first wave waits for these stores when it is
-      // about to post its next row -- finish_pass -- by when they have long landed)
+      if (tid == 0) count_snp_deferred(iters);
+      // published before this workgroup joins the next exchange (not left to the wait in finish_pass: that one would
+      // stand behind the next gamma step's stores)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     if (tid < J) {
@@ -1029,9 +1053,12 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
 #pragma unroll
         for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(w_a + (size_t)k * np)[i] = wcur[k];
         if (is_lds(t)) {
+          WT gv[KT];
+          CT cv;
+          get_lgamma(t, gv, cv);
 #pragma unroll
-          for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = s_gam[lds_slot(t)][k][tid];
-          reinterpret_cast<CT *>(p.cnt)[i] = s_cn[lds_slot(t)][tid];
+          for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = gv[k];
+          reinterpret_cast<CT *>(p.cnt)[i] = cv;
         }
       }
     }
@@ -1052,6 +1079,13 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       W->nrows = 0u;
       W->epoch = epoch_now;
       ctl->xseq = xseq0 + xcount;
+      ctl->total_passes = tp_run;
+      ctl->last_iters = last_it;
+      if (p.host_error) {
+        __hip_atomic_store(p.host_error + 1, (unsigned long long)last_it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.host_error + 2, tp_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the histogram atomics of this thread have landed)
 #ifdef TSAMD_SCHED_TIME
       if (n_sched >= 16u)
         printf("ts_schedule n=%u exchanges=%u | per SNP (us): head %.2f gamma %.2f first pass %.2f later passes %.2f tail %.2f | "
@@ -1060,6 +1094,10 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
                tk_fold * 0.01 / n_sched, tk_epi * 0.01 / n_sched, tk_sweep * 0.01 / n_sched, (wall_clock64() - tk_start) * 0.01);
 #endif
     }
+    __syncthreads();
+    if (p.host_error && tid < (uint32_t)TSAMD_PASS_HIST_BINS)  // the histogram's pinned host mirror (tsamd_pass_histogram reads it after a synchronise)
+      __hip_atomic_store(p.host_error + 3 + tid, __hip_atomic_load(&ctl->pass_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 #undef TSAMD_TK
 }

@@ -159,29 +159,37 @@ def test_trajectory_matches_oracle(ts, n, l, k):
 
 
 @pytest.mark.parametrize("n,l,k", [(4000, 64, 8), (90000, 40, 5), (600000, 40, 8)])
-def test_run_schedule_equals_snp_updates_bitwise(ts, n, l, k):
-    """run_schedule (hipGraph replay) == n x snp_update (eager), bit for bit, and is
-    reproducible run to run (fixed reduction order) -- also at sizes where a pass leaves more
-    partial rows than one load batch and the plain pass runs 512-thread workgroups."""
+def test_run_schedule_equals_snp_updates_bitwise(ts, n, l, k, monkeypatch):
+    """run_schedule == n x snp_update, bit for bit, and is reproducible run to run (fixed reduction order) -- also
+    at sizes where a thread of the resident kernels owns many individuals.  From 4M weights per GPU on, single-entry
+    calls are routed through the launch-per-SNP kernels by default (faster for that shape, include/tsamd.h): there
+    the bitwise statement holds with TSAMD_SINGLE_ROUTE=0, and the routed calls agree to rounding."""
     rng = np.random.default_rng(9)
     locs = rng.integers(0, l, size=37).astype(np.uint32)
+    routed = n * k >= 4 << 20
     outs = []
-    for mode in ("eager", "schedule", "schedule", "nograph"):
+    for mode in ("eager", "schedule", "schedule", "nograph") + (("eager-routed",) if routed else ()):
         flags = ts.FLAG_NO_GRAPH if mode == "nograph" else 0
+        monkeypatch.setenv("TSAMD_SINGLE_ROUTE", "1" if mode == "eager-routed" else "0")
         eng, _, _ = make_pair(ts, n, l, k, 77, flags=flags)
         with eng:
-            if mode == "eager":
+            if mode.startswith("eager"):
                 for loc in locs:
                     eng.snp_update(int(loc))
             else:
                 eng.run_schedule(locs)
                 eng.synchronize()
             outs.append((eng.get_lambda(), eng.get_gamma(), eng.get_counts(), eng.total_passes()))
-    for o in outs[1:]:
+    for o in outs[1:4]:
         assert np.array_equal(o[0], outs[0][0])
         assert np.array_equal(o[1], outs[0][1])
         assert np.array_equal(o[2], outs[0][2])
         assert o[3] == outs[0][3]
+    if routed:
+        o = outs[4]
+        assert not np.array_equal(o[0], outs[0][0]), "the routed calls ran the same kernels?"
+        assert rel_err(o[0], outs[0][0]) < 1e-10 and rel_err(o[1], outs[0][1]) < 1e-10
+        assert np.array_equal(o[2], outs[0][2]) and o[3] == outs[0][3]
 
 
 @pytest.mark.parametrize("n,l,k", [(3000, 32, 6), (90000, 32, 6)])

@@ -119,8 +119,12 @@ def test_benchmarked_geometry_matches_oracle(ts, n, k, thresh):
             e_lam, e_gam = rel_err(lam_d, lam_o), rel_err(gam_d, gam_o)
             assert e_lam < 1e-9 and e_gam < 1e-9, (launch, mode, e_lam, e_gam)
             res[mode] = (lam_d, gam_d)
-        # within a launch mode: one call per schedule == one call per update, bit for bit
-        assert np.array_equal(res["graph"][0], res["eager"][0]) and np.array_equal(res["graph"][1], res["eager"][1]), launch
+        # within a launch mode: one call per schedule == one call per update, bit for bit -- except in the default mode
+        # from 4M weights per GPU on, where single-entry calls are routed through the launch-per-SNP kernels (tsamd.h)
+        if launch is None and len(launch_modes) == 3 and n * k >= 4 << 20:
+            assert rel_err(res["graph"][0], res["eager"][0]) < 1e-10 and rel_err(res["graph"][1], res["eager"][1]) < 1e-10
+        else:
+            assert np.array_equal(res["graph"][0], res["eager"][0]) and np.array_equal(res["graph"][1], res["eager"][1]), launch
         per_mode[launch] = res["graph"]
     # the modes differ by the order in which the workgroups' partial rows are added
     for launch, got in per_mode.items():
