@@ -660,12 +660,12 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   // the 2-bit codes of a column for this thread's items, packed into one register (an item the thread does not own:
   // missing).  In two steps, so that the words of the NEXT SNP's column can be requested a SNP ahead and packed when
   // they are needed.
-  auto load_words = [&](uint32_t loc_, uint32_t (&word)[kItems]) {
+  auto load_words = [&](uint32_t loc_, auto &word) {
     const uint32_t *col = reinterpret_cast<const uint32_t *>(p.bed + (size_t)loc_ * p.colstride);
 #pragma unroll
     for (int t = 0; t < kItems; ++t) word[t] = col[item_or_last((uint32_t)t) / RC::kItemsPerWord];
   };
-  auto pack_codes = [&](const uint32_t (&word)[kItems]) -> uint32_t {
+  auto pack_codes = [&](const auto &word) -> uint32_t {
     uint32_t out = 0u;
 #pragma unroll
     for (int t = 0; t < kItems; ++t) {
@@ -731,8 +731,11 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   double lam_old = 0.0, eb_used = 0.0;
   double b0[BS ? KT : 1], b1[BS ? KT : 1], acc0[KT], acc1[KT];
   bool complete = false;
-  uint32_t codes = load_codes(sched[0] & 0x7fffffffu);  // (every later SNP's column is requested while its predecessor runs)
-  uint32_t nword[kItems];
+  // every later SNP's column is requested while its predecessor runs -- except at K = 16, whose 128 resident doubles
+  // per thread leave no room for the words in flight (36 bytes of scratch otherwise): it loads them when the SNP starts
+  constexpr bool kColAhead = KT != 16;
+  uint32_t codes = kColAhead ? load_codes(sched[0] & 0x7fffffffu) : 0u;
+  uint32_t nword[kColAhead ? kItems : 1];
   auto begin_pass = [&]() {
     fresh();
     iters += 1u;
@@ -860,6 +863,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       s_eb[tid] = local ? s_peb[tid] : neb;
     }
     fresh();
+    if constexpr (!kColAhead) codes = load_codes(loc);
     __syncthreads();
     iters = 0u;
     TSAMD_TK(tk_head);
@@ -977,7 +981,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       nlam = __hip_atomic_load(&p.lam[(size_t)(ent_n & 0x7fffffffu) * J + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       neb = __hip_atomic_load(&p.eb[(size_t)(ent_n & 0x7fffffffu) * J + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    load_words(ent_n & 0x7fffffffu, nword);  // (the next SNP's column: packed at the end of this SNP)
+    if constexpr (kColAhead) load_words(ent_n & 0x7fffffffu, nword);  // (the next SNP's column: packed at the end of this SNP)
     while (!complete) {
       begin_pass();
       sweep();
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     }
     pcodes = codes;
     fresh();
-    codes = pack_codes(nword);
+    if constexpr (kColAhead) codes = pack_codes(nword);
     do_gamma = hol == 0u;
     prev_valid = true;
     prev_loc = loc;
