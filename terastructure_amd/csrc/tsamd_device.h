@@ -232,41 +232,6 @@ __device__ __forceinline__ double exp_nonpos(double d) {
   return __builtin_amdgcn_ldexp(p, (int)n);  // (v_cvt_i32_f64 saturates; 2^-huge flushes to 0)
 }
 
-// The same through a 64-entry table of 2^(j/64) (kept in LDS by the caller): d = (64 m + j) ln2/64 + r with
-// |r| <= ln2/128, exp(d) = 2^m * tab[j] * exp(r), degree-5 Taylor polynomial (truncation 3.4e-17): five vector
-// operations fewer than exp_nonpos.  Used by the whole-schedule kernel, whose gamma step is bound by its arithmetic.
-__device__ __constant__ const double kExp2Tab[64] = {
-    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
-    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
-    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
-    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
-    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
-    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
-    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
-    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
-    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
-    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
-    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
-    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
-    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
-    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
-    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
-    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
-__device__ __forceinline__ double exp_nonpos_tab(double d, const double *tab) {
-  const double n = __builtin_rint(d * 92.332482616893656877);  // 64 / ln 2
-  double r = fma(n, -0x1.62e42fe000000p-7, d);                 // ln2/64, high part (n * hi is exact)
-  r = fma(n, -0x1.f473de6af278fp-36, r);
-  const int ni = (int)n;
-  const double t = tab[ni & 63];
-  double p = 1.0 / 120.0;
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return __builtin_amdgcn_ldexp(t * p, ni >> 6);  // (arithmetic shift: floor division for negative n)
-}
-
 // Cross-lane moves of the wave fold, all on the vector ALU (no trip through the LDS pipe):
 //  * pair_add<32|16>(a, b): v_permlane32_swap / v_permlane16_swap (gfx950) exchange the upper
 //    half-wave (odd 16-lane rows) of a with the lower half-wave (even rows) of b, after which

@@ -213,28 +213,10 @@ struct ResCodes {
   static constexpr uint32_t kMissing = VEC == 2 ? 0x5u : 0x1u;  // PLINK 01 for every individual of the item
 };
 
-#ifdef TSAMD_EXP_TABLE  // (experiment, tools/variant.sh: the exponentials of the gamma step through a 2^(j/64) table in LDS)
-#define TSAMD_EXPD(x, tab) exp_nonpos_tab((x), (tab))
-#else
-#define TSAMD_EXPD(x, tab) exp_nonpos(x)
-#endif
-// gamma_to_w (tsamd_kernels.h) with the exponential above
-template <int KT>
-__device__ __forceinline__ void gamma_to_w_res(const double (&g)[KT], double (&w)[KT], const double *tab) {
-  double z[KT], a[KT];
-  double amax = -1.0e300;
-#pragma unroll
-  for (int k = 0; k < KT; ++k) {
-    exp_digamma_split(g[k], z[k], a[k]);
-    amax = fmax(amax, a[k]);
-  }
-#pragma unroll
-  for (int k = 0; k < KT; ++k) w[k] = z[k] * TSAMD_EXPD(a[k] - amax, tab);
-}
 // w = exp(psi(g)) up to a per-individual factor, like gamma_to_w, holding K instead of 2K temporaries across the
 // maximum (z = g + 10 is formed again instead of kept): the large-K instantiations live on their registers
 template <int KT>
-__device__ __forceinline__ void gamma_to_w_lean(const double (&g)[KT], double (&w)[KT], const double *tab) {
+__device__ __forceinline__ void gamma_to_w_lean(const double (&g)[KT], double (&w)[KT]) {
   double a[KT];
   double amax = -1.0e300;
 #pragma unroll
@@ -247,7 +229,7 @@ __device__ __forceinline__ void gamma_to_w_lean(const double (&g)[KT], double (&
   for (int k = 0; k < KT; ++k) {
     double gk = g[k];
     asm volatile("" : "+v"(gk));  // (opaque: otherwise the z of the first loop is kept alive instead)
-    w[k] = (gk + 10.0) * TSAMD_EXPD(a[k] - amax, tab);
+    w[k] = (gk + 10.0) * exp_nonpos(a[k] - amax);
   }
 }
 
@@ -265,36 +247,19 @@ __device__ __forceinline__ void res_consume(const typename Lanes<VEC>::T (&wv)[K
     bool ok;
     code_weights((code >> (2 * v)) & 3u, mom, dad, ok);
     double s0 = 0.0, s1 = 0.0;
-#ifdef TSAMD_TREE_SUM  // (experiment: the normalisers as two half-length chains)
-    double t0 = 0.0, t1 = 0.0;
-#endif
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       double wk;
       if constexpr (VEC == 2) wk = v ? wv[k].y : wv[k].x; else wk = wv[k];
-      double bx, by;
       if constexpr (BS) {
-        bx = b0[k];
-        by = b1[k];
+        s0 = fma(wk, b0[k], s0);
+        s1 = fma(wk, b1[k], s1);
       } else {
         const double2 b = s_b[k];
-        bx = b.x;
-        by = b.y;
+        s0 = fma(wk, b.x, s0);
+        s1 = fma(wk, b.y, s1);
       }
-#ifdef TSAMD_TREE_SUM
-      if (k & 1) {
-        t0 = fma(wk, bx, t0);
-        t1 = fma(wk, by, t1);
-        continue;
-      }
-#endif
-      s0 = fma(wk, bx, s0);
-      s1 = fma(wk, by, s1);
     }
-#ifdef TSAMD_TREE_SUM
-    s0 += t0;
-    s1 += t1;
-#endif
     c0[v] = mom * fast_rcp(s0);
     c1[v] = dad * fast_rcp(s1);
   }
@@ -543,7 +508,7 @@ constexpr int sched_lds_items(int k, int items, int vec) {
 #ifdef TSAMD_SCHED_LDS_ITEMS  // (experiments, tools/variant.sh)
   return TSAMD_SCHED_LDS_ITEMS < items ? TSAMD_SCHED_LDS_ITEMS : items;
 #else
-  const int small = 1536 + 18 * 2 * k * 8;  // the K x 2 arrays below (and the experiment's exponential table)
+  const int small = 1536 + 18 * 2 * k * 8;  // the K x 2 arrays below
   const int per_item = (k * 8 + 4) * vec * 256, n = (160 * 1024 - small) / per_item;
   return n < items ? n : items;
 #endif
@@ -571,11 +536,6 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   __shared__ double s_drow[J], s_dlam[J], s_dolam[J], s_doeb[J], s_ddiff[J];  // the deferred last pass of the previous SNP
   __shared__ double s_red[kWaves * J];
   __shared__ int s_alive[4];
-#ifdef TSAMD_EXP_TABLE
-  __shared__ double s_exp2[64];
-#else
-  double *const s_exp2 = nullptr;
-#endif
   // gamma (and c_n) of kLds of a thread's items stay in LDS for the whole launch, spread evenly over the items; the
   // gamma step streams the others from memory, one streamed item ahead.  Memory sees them again when the launch ends.
   constexpr int kLds = sched_lds_items(KT, kItems, VEC);
@@ -613,9 +573,6 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     return;
   }
   if (tid < 4) s_alive[tid] = 1;
-#ifdef TSAMD_EXP_TABLE
-  if (tid < 64) s_exp2[tid] = kExp2Tab[tid];
-#endif
   __syncthreads();
   uint32_t xcount = 1u;  // exchanges of this launch
   // the entry exchange: empty rows, nothing modified yet.  All workgroups resident?
@@ -903,7 +860,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
           const double e = c0 * (wx[k] * sbv[2 * k]) + c1 * (wx[k] * sbv[2 * k + 1]);
           gx[k] += rho * (p.alpha + p.gamma_scale * e - gx[k]);
         }
-        if constexpr (KT <= 8) gamma_to_w_res<KT>(gx, wx, s_exp2 + zo); else gamma_to_w_lean<KT>(gx, wx, s_exp2 + zo);
+        if constexpr (KT <= 8) gamma_to_w<KT>(gx, wx); else gamma_to_w_lean<KT>(gx, wx);
         cn = ok ? cn + 1u : cn;
       };
       constexpr int kFirstStreamed = sched_next_streamed(-1, kLds, kItems);

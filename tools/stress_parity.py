@@ -1,5 +1,6 @@
 """Randomised parity stress (not part of the test suite): many (n, k, missing rate, pass cap, launch mode)
-combinations, device vs oracle: inner pass counts exactly, lambda / gamma to 1e-9.
+combinations, device vs oracle: inner pass counts exactly, lambda / gamma to 1e-9.  K = 1 ... 40 covers the resident
+kernels' every geometry (16 ... 3 individuals per thread, rows exchanged over 1 ... 4 waves) and the run-time-K fallback.
 python tools/stress_parity.py [cases] [seed]"""
 import os, sys
 import numpy as np
@@ -13,8 +14,10 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for c in range(cases):
-    n = int(rng.choice([1, 7, 64, 200, 513, 1000, 2999, 5000, 12000, 70001, 150000]))
+    n = int(rng.choice([1, 7, 64, 200, 513, 1000, 2999, 5000, 12000, 70001, 150000, 150000, 260000]))
     k = int(rng.integers(1, 41))
+    if n > 200000:
+        k = min(k, 24)   # (the oracle's time per case)
     l = 12
     miss = float(rng.choice([0.0, 0.02, 0.3]))
     cap = int(rng.choice([1, 3, 10, 10, 10, 40]))
@@ -24,7 +27,7 @@ for c in range(cases):
     g = init_gamma(n, k, seed + 1)
     if rng.random() < 0.2:
         g = g * 10.0 ** rng.uniform(-2, 3, size=g.shape)
-    eng = ts.Engine(n, l, k, max_inner=cap); orc = op.Oracle(n, l, k, online_iterations=cap, nthreads=8 if n > 20000 else 1)
+    eng = ts.Engine(n, l, k, max_inner=cap); orc = op.Oracle(n, l, k, online_iterations=cap, nthreads=16 if n > 20000 else 1)
     mode = int(rng.integers(0, 4))   # 3: whatever tsamd_create chose
     if mode < 3:
         try:
