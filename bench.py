@@ -102,11 +102,15 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
     import oracle_py as op
     from terastructure_amd import dist as tdist
 
-    # three candidates: the RCCL all-reduce, peer-to-peer stores with one launch per pass ("p2p"), and ts_schedule with
-    # its in-launch exchange across the ranks ("p2p_schedule": one launch per rank and schedule; K <= 8 and shards of
-    # 8 ... 256 workgroups only)
+    # candidates: the RCCL all-reduce, peer-to-peer stores with one launch per pass ("p2p"), and ts_schedule with its
+    # in-launch exchange across the ranks ("p2p_schedule": one launch per rank and schedule; K <= 32 and shards that fit
+    # the register file and fill 8 ... 256 workgroups)
+    # ... and "p2p_schedule3": the same launch with THREE levels -- only the eight group leaders of a rank poll the world x 8
+    # rows that arrive over xGMI and hand the total to their members (TSAMD_SCHEDULE_GATHER=leaders): one local hop more,
+    # 32 x less polling of the fine-grained buffer.  Which of the two is faster on a node only the node can say.
     forced = os.environ.get("TSAMD_EXCHANGE", "auto").lower()
-    modes = [forced] if forced in ("rccl", "p2p", "p2p_schedule") else ["rccl", "p2p", "p2p_schedule"]
+    all_modes = ["rccl", "p2p", "p2p_schedule", "p2p_schedule3"]
+    modes = [forced] if forced in all_modes else all_modes
     l = 32
     sb, sc = shard
     beta = np.random.default_rng(7).uniform(0.05, 0.95, size=(l, k))
@@ -117,6 +121,7 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
     for mode in modes:
         final[mode] = None
         report["valid"][mode] = False
+        os.environ["TSAMD_SCHEDULE_GATHER"] = "leaders" if mode == "p2p_schedule3" else "all"   # (read when the exchange is connected)
         e = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
         try:
             e.synth_genotypes(theta_shard, beta, seed=11)
@@ -130,7 +135,7 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
             whole = e.launch_info()["kernels_per_snp"] == 0   # (the same on every rank: it depends on the configuration only)
             if mode == "p2p" and whole:
                 e.set_launch_mode(ts.LAUNCH_PER_PASS)
-            if mode == "p2p_schedule" and not whole:
+            if mode.startswith("p2p_schedule") and not whole:
                 report["valid"].pop(mode)
                 continue                                       # the shards do not qualify: not a candidate
             if want is None:  # the oracle's answer for the first 6 updates, once, on rank 0
@@ -200,7 +205,7 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
                 report["valid"][a] = report["valid"][b] = False
     rates = report["updates_per_s"]
     chosen = None
-    for m in ("rccl", "p2p", "p2p_schedule"):   # (later ones win ties: fewer launches)
+    for m in all_modes:   # (later ones win ties: fewer launches)
         if report["valid"].get(m) and (chosen is None or rates[m] >= rates[chosen]):
             chosen = m
     report["chosen"] = chosen
@@ -286,6 +291,7 @@ def main():
 
         err = None
         try:
+            os.environ["TSAMD_SCHEDULE_GATHER"] = "leaders" if exchange == "p2p_schedule3" else "all"
             (tdist.bootstrap_comm if exchange == "rccl" else tdist.bootstrap_p2p)(eng, dist)
             if exchange == "p2p" and eng.launch_info()["kernels_per_snp"] == 0:
                 eng.set_launch_mode(ts.LAUNCH_PER_PASS)   # (the in-launch exchange did not pass, or was slower)

@@ -495,6 +495,11 @@ void activate_xchg(tsamd_ctx *c) {
   const bool hooks = (c->cfg.flags & TSAMD_FLAG_TEST_HOOKS) != 0u;
   c->p.xchg_test_delay = hooks ? env_u32("TSAMD_TEST_XCHG_DELAY_US", 0) * 100u : 0u;
   c->p.xchg_test_noguard = hooks ? env_u32("TSAMD_TEST_XCHG_NOGUARD", 0) : 0u;
+  {
+    // ts_schedule across ranks: who gathers the ranks' group sums (all ranks must agree: the environment of a job)
+    const char *g = getenv("TSAMD_SCHEDULE_GATHER");
+    c->p.xchg_gather_leaders = (g && strcmp(g, "leaders") == 0) ? 1u : 0u;
+  }
   c->split = true;
   c->resident = c->persistent = c->can_resident = c->can_persistent = false;
   c->p2p = true;

@@ -121,6 +121,8 @@ struct DevParams {
                                    // the most recently completed SNP (Ctl::last_iters), so tsamd_snp_update needs no copy either
   ResXchg *res;              // resident kernels: their exchange buffer (NULL: the context never qualified for them)
   uint32_t probe_ticks;      // resident kernels: bound of the launch's first exchange in 10 ns ticks (are all workgroups resident?)
+  uint32_t xchg_gather_leaders; // ts_schedule on several GPUs: only the group leaders gather the ranks' group sums and hand the
+                                // total to their members (three levels) instead of every workgroup polling world x 8 rows (two)
   uint32_t xchg_test_delay;  // test hook (TSAMD_TEST_XCHG_DELAY_US): stall between flag wait and row reads, 10 ns ticks
   uint32_t xchg_test_noguard; // test hook (TSAMD_TEST_XCHG_NOGUARD): skip the slot-reuse guard (to show the test sees the hazard)
   double alpha, eta0, eta1, nodetau0, nodekappa, gamma_scale, thresh;

@@ -192,11 +192,20 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
         alive = res_sweep<kResGroups / 2, __HIP_MEMORY_SCOPE_AGENT>(L::sums(xb, region, tag & 1u, 0), GR, 32u * cb, tag, nvalid, groups, v2, &xb->abort_word,
                                                                     p.host_error, code, ticks, lane) && alive;
         s = res_sum<kResGroups / 2>(v2, lane);
-      } else {  // (every rank runs at least 8 workgroups -- the host checks -- so all world * 8 rows exist)
+      } else if (p.xchg_gather_leaders == 0u || m == 0u) {
+        // (every rank runs at least 8 workgroups -- the host checks -- so all world * 8 rows exist)
         unsigned v2[WR];
         alive = res_sweep<WR, __HIP_MEMORY_SCOPE_SYSTEM>(L::rank_sums(p.xchg, region, tag & 1u, 0), GR, 32u * cb, tag, nvalid,
                                                          p.xchg_world * (uint32_t)kResGroups, v2, &xb->abort_word, p.host_error, code, ticks, lane) && alive;
         s = res_sum<WR>(v2, lane);
+        // three levels (TSAMD_SCHEDULE_GATHER=leaders): only the eight leaders of a rank poll the world x 8 rows; each hands
+        // the total -- the same bits on every leader of every rank -- to the members of its group through its local row
+        if (p.xchg_gather_leaders != 0u && lane < nvalid && !(lane & 1u)) res_post(L::sums(xb, region, tag & 1u, g) + 32u * cb + lane, tag, s, 0);
+      } else {
+        unsigned v1[1];
+        alive = res_sweep<1, __HIP_MEMORY_SCOPE_AGENT>(L::sums(xb, region, tag & 1u, g), GR, 32u * cb, tag, nvalid, 1u, v1, &xb->abort_word, p.host_error,
+                                                       code, ticks, lane) && alive;
+        s = res_sum<1>(v1, lane);
       }
       if (lane < nvalid && !(lane & 1u)) s_tot[region * J + 16u * cb + (lane >> 1)] = s;
     }

@@ -42,7 +42,7 @@ def main():
         cand = np.nonzero(y[loc] != 3)[0]
         eng.set_heldout(int(loc), rng.choice(cand, size=max(1, n // 50), replace=False))
     if mode == "p2p":
-        tdist.bootstrap_p2p(eng, d)
+        tdist.bootstrap_p2p(eng, d)   # (TSAMD_SCHEDULE_GATHER=leaders in the environment: three-level cross-rank exchange)
     else:
         err = None
         try:

@@ -154,6 +154,27 @@ def test_sharded_schedule_kernel_matches_oracle(tmp_path, world, n, k, thresh, m
         assert np.array_equal(res[0]["cnt"], ref[0]["cnt"])
 
 
+@pytest.mark.parametrize("world,n,k,thresh", [(2, 60_000, 8, 8.0), (4, 90_000, 16, None), (8, 125_000, 20, None), (3, 40_000, 5, None)])
+def test_sharded_schedule_kernel_three_levels(tmp_path, world, n, k, thresh):
+    """The same with TSAMD_SCHEDULE_GATHER=leaders: only a rank's eight group leaders poll the world x 8 rows the ranks send
+    each other; every other workgroup takes the total from its own group's leader (one local hop more, far less polling of
+    the fine-grained buffer).  Against the oracle; replicated state bitwise equal on all ranks; the same bits as the
+    two-level exchange (both add the rows in (rank, group) order)."""
+    l, seed, nsnp = 24, 77, 40
+    env, over = {"TS_EXPECT_KPS": "0", "TSAMD_SCHEDULE_GATHER": "leaders"}, {}
+    if thresh is not None:
+        env["TS_CONV_THRESH"] = str(thresh)
+        over["meanchangethresh"] = thresh
+    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp, extra_env=env)
+    orc, its = _oracle_run(n, l, k, seed, nsnp, **over)
+    _assert_ranks_match(res, orc, its)
+    if world == 2:
+        (tmp_path / "two").mkdir()
+        env2 = dict(env, TSAMD_SCHEDULE_GATHER="all")
+        ref = _run_ranks(tmp_path / "two", "p2p", world, n, l, k, seed, nsnp, extra_env=env2)
+        assert np.array_equal(res[0]["lam"], ref[0]["lam"]) and np.array_equal(res[0]["gamma"], ref[0]["gamma"])
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_ranks_switch_launch_modes_mid_run(tmp_path, world):
     """ts_schedule (in-launch exchange across the ranks) -> one launch per pass (epoch-tagged peer-to-peer rows with the
