@@ -118,14 +118,41 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
     locs[:6] = [3, 1, 3, 7, 0, 5]
     report = {"updates_per_s": {}, "rel_err_vs_oracle": {}, "valid": {}}
     final, want = {}, None
+    def step(fn):
+        """Run fn on this rank; (it succeeded on EVERY rank, its result here, its exception here).  Everything that can fail
+        on one rank alone goes through this, so that all ranks always issue the same sequence of collectives: a rank that
+        skipped a gather because ITS kernels timed out would leave the others waiting in it until gloo's timeout."""
+        out, err = None, None
+        try:
+            out = fn()
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+        return tdist.all_ok(err is None, dist), out, err
+
+    def note(mode, what, err):
+        errs = [None] * world if rank == 0 else None
+        dist.gather_object(None if err is None else f"{type(err).__name__}: {err}", errs, dst=0)
+        if rank == 0:
+            print(f"[bench] exchange self-test, {mode}: {what} failed on rank(s) "
+                  f"{ {r: m for r, m in enumerate(errs) if m} }", file=sys.stderr, flush=True)
+
     for mode in modes:
         final[mode] = None
         report["valid"][mode] = False
         os.environ["TSAMD_SCHEDULE_GATHER"] = "leaders" if mode == "p2p_schedule3" else "all"   # (read when the exchange is connected)
-        e = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
+        holder = {}
+
+        def create():
+            holder["e"] = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
+            holder["e"].synth_genotypes(theta_shard, beta, seed=11)
+            holder["e"].set_gamma(gamma_full[sb:sb + sc])
+
+        ok, _, err = step(create)
+        e = holder.get("e")
         try:
-            e.synth_genotypes(theta_shard, beta, seed=11)
-            e.set_gamma(gamma_full[sb:sb + sc])
+            if not ok:
+                note(mode, "set-up", err)
+                continue
             try:
                 (tdist.bootstrap_comm if mode == "rccl" else tdist.bootstrap_p2p)(e, dist)
             except Exception as exc:  # noqa: BLE001 -- raised on every rank together
@@ -139,59 +166,73 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
                 report["valid"].pop(mode)
                 continue                                       # the shards do not qualify: not a candidate
             if want is None:  # the oracle's answer for the first 6 updates, once, on rank 0
-                cols = np.stack([e.download_bed(j) for j in range(l)])          # [l][shard bytes]
+                ok, cols, err = step(lambda: np.stack([e.download_bed(j) for j in range(l)]))          # [l][shard bytes]
+                if not ok:
+                    note(mode, "reading the columns back", err)
+                    continue
                 parts = gather_bytes(cols, dist, rank)
-                if rank == 0:
+
+                def oracle():
+                    if rank != 0:
+                        return ()
                     orc = op.Oracle(n, l, k, nthreads=cores)
                     orc.load_bed_payload(np.concatenate(parts, axis=1)[:, :(n + 3) // 4])
                     orc.set_gamma(gamma_full)
                     for loc in locs[:6]:
                         orc.snp_update(int(loc))
-                    want = (orc.lambda_(), orc.gamma(), orc.c_indiv())
+                    out = (orc.lambda_(), orc.gamma(), orc.c_indiv())
                     orc.close()
-                else:
-                    want = ()
-            res, err, dt, e6 = None, None, 0.0, float("inf")
-            try:
-                e.run_schedule(locs[:6])
-                e.synchronize()
-                lam6 = e.get_lambda()
-                gam6 = tdist.gather_rows(e.get_gamma(), n, dist, ts.shard_range)
-                cnt6 = tdist.gather_rows(e.get_counts().astype(np.float64)[:, None], n, dist, ts.shard_range)[:, 0]
+                    return out
+
+                ok, want_, err = step(oracle)
+                if not ok:
+                    note(mode, "the oracle", err)
+                    continue
+                want = want_
+            res, dt, e6 = None, 0.0, float("inf")
+            ok, st6, err = step(lambda: (e.run_schedule(locs[:6]), e.synchronize(), e.get_lambda(), e.get_gamma(),
+                                         e.get_counts().astype(np.float64)[:, None])[2:])
+            if ok:
+                gam6 = tdist.gather_rows(st6[1], n, dist, ts.shard_range)
+                cnt6 = tdist.gather_rows(st6[2], n, dist, ts.shard_range)[:, 0]
                 if rank == 0:
-                    e6 = max(rel_err(lam6, want[0]), rel_err(gam6, want[1]))
+                    e6 = max(rel_err(st6[0], want[0]), rel_err(gam6, want[1]))
                     if not np.array_equal(cnt6, want[2]):
                         e6 = float("inf")
-                e.run_schedule(locs[6:60])
-                e.synchronize()
+                ok, _, err = step(lambda: (e.run_schedule(locs[6:60]), e.synchronize()))
+            if ok:
                 dist.barrier()
-                t0 = time.perf_counter()
-                e.run_schedule(locs[60:])
-                e.synchronize()
-                dt = time.perf_counter() - t0
-                res = (e.get_lambda(), e.get_gamma())
-            except Exception as exc:  # noqa: BLE001
-                err = exc
+
+                def timed():
+                    t0 = time.perf_counter()
+                    e.run_schedule(locs[60:])
+                    e.synchronize()
+                    return time.perf_counter() - t0, (e.get_lambda(), e.get_gamma())
+
+                ok, out, err = step(timed)
+                if ok:
+                    dt, res = out
             t6 = torch.tensor([e6 if rank == 0 else 0.0], dtype=torch.float64)
             dist.broadcast(t6, src=0)
             e6 = float(t6.item())
             report["rel_err_vs_oracle"][mode] = e6 if np.isfinite(e6) else None
-            if tdist.all_ok(err is None, dist):
+            if ok:
                 tt = torch.tensor([dt], dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 report["updates_per_s"][mode] = round((len(locs) - 60) / float(tt.item()), 1)
                 # (to read the first real multi-GPU run against the single-GPU figures: DESIGN.md section 5 predicts the
-                # per-pass cost of each candidate; one GPU: 6.2 us per pass inside ts_schedule, 2.9 of them in the exchange)
+                # per-pass cost of each candidate; one GPU: 6.1 us per pass inside ts_schedule, 3.1 of them in the exchange)
                 report.setdefault("us_per_update", {})[mode] = round(float(tt.item()) / (len(locs) - 60) * 1e6, 2)
                 report.setdefault("us_per_pass", {})[mode] = round(float(tt.item()) / (len(locs) - 60) * 1e6 / 10.0, 2)
                 if e6 < SELFTEST_TOL:
                     final[mode] = res
                     report["valid"][mode] = True
-            elif rank == 0:
-                print(f"[bench] exchange self-test, {mode}: run failed ({err})", file=sys.stderr, flush=True)
+            else:
+                note(mode, "the run", err)
         finally:
             dist.barrier()
-            e.close()
+            if e is not None:
+                e.close()
             dist.barrier()
     # candidates that matched the oracle after 6 updates must also agree with each other after 260
     ok = [m for m in modes if final.get(m) is not None]
@@ -245,8 +286,11 @@ def main():
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # (the longest legitimate gap between two collectives is rank 0 running the oracle for the self-test: seconds)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=6))
         fail_together(oracle_ok, dist, "the exchange self-test needs oracle/libts_oracle.so on rank 0")
 
     import torch
@@ -285,11 +329,16 @@ def main():
         # an exchange that did not reproduce the oracle is never timed
         fail_together(exchange is not None, dist,
                       f"no exchange passed its self-test on this node: {json.dumps(exchange_report)}")
-    eng = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
+    # (every step that can fail on one rank alone ends in fail_together: no rank is left in a collective a dead peer skipped)
+    eng, err = None, None
+    try:
+        eng = ts.Engine(n, l, k, device=local_rank, rank=rank, world=world)
+    except Exception as exc:  # noqa: BLE001
+        err = exc
+    fail_together(err is None, dist, f"engine creation: {err}")
     if world > 1:
         from terastructure_amd import dist as tdist
 
-        err = None
         try:
             os.environ["TSAMD_SCHEDULE_GATHER"] = "leaders" if exchange == "p2p_schedule3" else "all"
             (tdist.bootstrap_comm if exchange == "rccl" else tdist.bootstrap_p2p)(eng, dist)
@@ -299,14 +348,18 @@ def main():
             err = exc
         fail_together(err is None, dist, f"exchange bootstrap: {err}")
 
-    chunk = 1 << 17
-    brng = np.random.default_rng(args.seed + 1)
-    for l0 in range(0, l, chunk):
-        beta = brng.uniform(0.05, 0.95, size=(min(chunk, l - l0), k))
-        eng.synth_genotypes(theta, beta, first_loc=l0, seed=args.seed)
-    eng.set_gamma(gamma0[sb:sb + sc])
-    del theta, gamma0
-    eng.prepare()  # graphs captured + instantiated here, not inside the timed region
+    try:
+        chunk = 1 << 17
+        brng = np.random.default_rng(args.seed + 1)
+        for l0 in range(0, l, chunk):
+            beta = brng.uniform(0.05, 0.95, size=(min(chunk, l - l0), k))
+            eng.synth_genotypes(theta, beta, first_loc=l0, seed=args.seed)
+        eng.set_gamma(gamma0[sb:sb + sc])
+        del theta, gamma0
+        eng.prepare()  # graphs captured + instantiated here, not inside the timed region
+    except Exception as exc:  # noqa: BLE001
+        err = exc
+    fail_together(err is None, dist, f"set-up of the benchmark's data: {err}")
     try:
         # bring the device to its working clocks before the (possibly very short) warm-up: ~20 ms of the
         # bare streaming probes, which read the weights and write them back unchanged
@@ -384,182 +437,186 @@ def main():
     # once and keeps them in registers: its algorithmic bytes per launch are passes x the plain-pass bytes.
     roofline = None
     if not args.no_profile:
+      try:
         info = eng.launch_info()
-        kps = info["kernels_per_snp"]
-        mode = "schedule" if kps == 0 else "snp" if (kps == 2 and eng.cfg.max_inner > 2) else "pass"
-        pass_bytes = 8.0 * sc * k + sc / 4.0
-        first_bytes = 32.0 * sc * k + 8.0 * sc + sc / 2.0
+          kps = info["kernels_per_snp"]
+          mode = "schedule" if kps == 0 else "snp" if (kps == 2 and eng.cfg.max_inner > 2) else "pass"
+          pass_bytes = 8.0 * sc * k + sc / 4.0
+          first_bytes = 32.0 * sc * k + 8.0 * sc + sc / 2.0
 
-        def pmc_record(want):
-            pmc = os.path.join(ROOT, "profiles", "pass_kernel_pmc.json")
-            try:
-                for rec in json.load(open(pmc)).get("records", []):
-                    if rec.get("n") == n and rec.get("k") == k and rec.get("n_gpus") == world and rec.get("mode", "pass") == want:
-                        return rec
-            except Exception:  # noqa: BLE001
-                pass
-            return {}
+          def pmc_record(want):
+              pmc = os.path.join(ROOT, "profiles", "pass_kernel_pmc.json")
+              try:
+                  for rec in json.load(open(pmc)).get("records", []):
+                      if rec.get("n") == n and rec.get("k") == k and rec.get("n_gpus") == world and rec.get("mode", "pass") == want:
+                          return rec
+              except Exception:  # noqa: BLE001
+                  pass
+              return {}
 
-        def profiled(nsteps):
-            """(profile_read dict, passes the device ran) over nsteps updates"""
-            eng.synchronize()
-            q0 = eng.total_passes()
-            eng.profile_enable(True)
-            eng.run_schedule(locs[args.warmup:args.warmup + nsteps])
-            eng.synchronize()
-            pr_ = eng.profile_read()
-            eng.profile_enable(False)
-            return pr_, eng.total_passes() - q0
+          def profiled(nsteps):
+              """(profile_read dict, passes the device ran) over nsteps updates"""
+              eng.synchronize()
+              q0 = eng.total_passes()
+              eng.profile_enable(True)
+              eng.run_schedule(locs[args.warmup:args.warmup + nsteps])
+              eng.synchronize()
+              pr_ = eng.profile_read()
+              eng.profile_enable(False)
+              return pr_, eng.total_passes() - q0
 
-        try:
-            read_us, rmw_us = eng.probe_stream(50)
-        except Exception as exc:  # noqa: BLE001 -- an extra, never fatal
-            read_us = rmw_us = None
-            print(f"[bench] stream probe skipped: {exc}", file=sys.stderr, flush=True)
+          try:
+              read_us, rmw_us = eng.probe_stream(50)
+          except Exception as exc:  # noqa: BLE001 -- an extra, never fatal
+              read_us = rmw_us = None
+              print(f"[bench] stream probe skipped: {exc}", file=sys.stderr, flush=True)
 
-        # the kernels of the launch-per-SNP / launch-per-pass sequence (the default mode for K > 8, sharded runs and
-        # shards beyond ~1M individuals; with the whole-schedule kernel they are timed in LAUNCH_PER_SNP mode, switched
-        # to for this measurement only)
-        per_snp = None
-        if mode == "schedule":
-            # (a sharded context has no launch-per-SNP mode: its other sequence is one launch per pass)
-            sub = ts.LAUNCH_PER_SNP if world == 1 else ts.LAUNCH_PER_PASS
-            eng.set_launch_mode(sub)
-            try:
-                pr, _ = profiled(min(args.steps, 300))
-            finally:
-                eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
-            sub_mode = "snp" if (world == 1 and eng.cfg.max_inner > 2) else "pass"
-        else:
-            pr, _ = profiled(min(args.steps, 300))
-            sub_mode = mode
-        if pr["pass_launches"] and pr["first_launches"]:
-            resident = sub_mode == "snp"
-            rec = pmc_record(sub_mode)
-            first_s = pr["first_ms"] / pr["first_launches"] * 1e-3
-            first_achieved = first_bytes / first_s / 1e9
-            passes_per_launch = pr["pass_launches"] / pr["first_launches"] if resident else 1.0
-            launches = pr["first_launches"] if resident else pr["pass_launches"]
-            avg_s = pr["pass_ms"] / launches * 1e-3
-            alg_bytes = passes_per_launch * pass_bytes
-            equiv = None
-            if resident:
-                # the resident kernel reads the weights from memory ONCE per SNP and runs the later passes from registers:
-                # its memory roofline is what it must move (weights once, one column), not passes x the plain-pass bytes
-                equiv = {"bytes_per_launch": alg_bytes, "GBps": round(alg_bytes / avg_s / 1e9, 1),
-                         "note": "passes x (8NK + N/4), the reference's dataflow, over this kernel's time: not a fraction of any peak"}
-                alg_bytes = pass_bytes
-                kernel = (f"ts_resident<{k}> (all {passes_per_launch:.3g} plain passes of a SNP in one launch: weights read once, "
-                          "kept in registers; partial rows exchanged inside the launch)")
-                note = ("achieved = the bytes the kernel must move per launch (the N x K weights once + one 2-bit column) over its "
-                        "launch time; `traffic` is the counter figure.  It is bound by neither memory nor arithmetic but by the "
-                        "in-launch exchange (about 3 us per pass with the ALU idle) plus the fp64 sweeps (2.6 us per pass at N = 1M, "
-                        "K = 8): per_pass_us x passes = avg_launch_us.  probe_read_us is a bare streaming read of the weights on this "
-                        "box (tsamd_probe_stream).")
-            else:
-                kernel = f"ts_pass<{k},false> (plain pass, max_inner - 1 launches per update)"
-                note = ("fabric-side bandwidth incl. Infinity Cache, not DRAM bandwidth: the pass re-reads the same weights (8NK "
-                        "bytes: 64 MB at N=1M, K=8) every launch and they stay in the 256 MiB Infinity Cache; FETCH_SIZE counts "
-                        "those hits.  probe_read_us is a bare streaming read of the same array with the same geometry on this "
-                        "box (tsamd_probe_stream): the second denominator.")
-            achieved = alg_bytes / avg_s / 1e9
-            per_snp = {
-                "bound": "hbm", "kernel": kernel,
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("hbm_bytes_per_launch"),
-                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bandwidth_equiv": equiv,
-                "avg_launch_us": round(avg_s * 1e6, 3), "launches_timed": launches,
-                "passes_per_launch": round(passes_per_launch, 3),
-                "per_pass_us": round(avg_s * 1e6 / passes_per_launch, 3),
-                "ceiling_note": note,
-                "probe_read_us": None if read_us is None else round(read_us, 3),
-                "frac_of_probe": None if read_us is None else round(read_us * 1e-6 / avg_s, 4),
-                "first_pass": {
-                    "kernel": f"ts_pass<{k},true> (first pass of a SNP + the previous SNP's gamma step, 1 launch per update)",
-                    "bound": "hbm", "achieved": round(first_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(first_achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("first_pass_hbm_bytes_per_launch"),
-                    "algorithmic_bytes_per_launch": first_bytes, "avg_launch_us": round(first_s * 1e6, 3),
-                    "launches_timed": pr["first_launches"],
-                    "probe_rmw_us": None if rmw_us is None else round(rmw_us, 3),
-                    "frac_of_probe": None if rmw_us is None else round(rmw_us * 1e-6 / first_s, 4),
-                },
-            }
-        if mode == "schedule":
-            # the dominant (only) kernel of the timed region: ONE launch runs the whole schedule.
-            nsteps = min(args.steps, 2000)
-            prs, ran = profiled(nsteps)
-            if prs["pass_launches"]:
-                rec = pmc_record("schedule")
-                launch_s = prs["pass_ms"] / prs["pass_launches"] * 1e-3
-                upd = nsteps / prs["pass_launches"]
-                ppu = ran / nsteps                                   # passes per update
-                # (1) what binds it: fp64 vector arithmetic at one wave per SIMD.  Flops per update from the SQ counters of
-                # a profiled launch when a record for this (N, K) is committed (profiles/pass_kernel_pmc.json, built from
-                # rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64), else the hand count of the kernel's own
-                # formulation (FMA = 2): a sweep is 8K + 20 per individual (two K-term normalisers, two reciprocals, 2K
-                # accumulations per parent), the gamma step 124K + 30 (normalisers 4K, update 12K, exp(psi) 108K).
-                hand = ppu * sc * (8.0 * k + 20.0) + sc * (124.0 * k + 30.0)
-                flops = rec.get("fp64_flops_per_update")
-                flops_src = "hand count of the kernel's formulation (no counter record for this N, K in profiles/pass_kernel_pmc.json)"
-                if flops:
-                    flops_src = "SQ_INSTS_VALU_*_F64 counters of a profiled launch: " + ", ".join(rec.get("flops_source_files", []))
-                else:
-                    flops = hand
-                tflops = flops * upd / launch_s / 1e12
-                # (2) memory: what the kernel itself must move per update -- gamma and c_n, read and written, of the items
-                # whose gamma is not kept in LDS, one 2-bit column -- and what the counters saw
-                vec, items, n_lds = resident_geometry(k)
-                moved = (16.0 * sc * k + 8.0 * sc) * (items - n_lds) / items + sc / 4.0
-                traffic = rec.get("hbm_bytes_per_update")
-                # (3) the reference's dataflow (SURVEY 8d): per update one first pass 32NK + 8N + N/2 and passes - 1 plain
-                # passes 8NK + N/4 -- what this kernel would have to move if the weights did not stay in registers
-                alg_bytes = (nsteps * first_bytes + max(0, ran - nsteps) * pass_bytes) / prs["pass_launches"]
-                # (4) latency: the in-launch exchanges, during which the vector ALU idles (in-kernel timers of the
-                # diagnostic build -DTSAMD_SCHED_TIME, recorded with the counters)
-                xus = rec.get("exchange_us_per_update")
-                roofline = {
-                    "bound": "fp64_valu",
-                    "kernel": (f"ts_schedule<{k}> (one launch = {upd:.0f} SNP updates: the gamma step and all {ppu:.3g} passes of every "
-                               "SNP; weights in registers from the first SNP to the last; partial rows exchanged inside the launch)"),
-                    "achieved": round(tflops, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4),
-                    "traffic": None if traffic is None else traffic * upd,
-                    "flops_per_update": flops, "flops_per_update_hand_count": hand, "flops_source": flops_src,
-                    "avg_launch_us": round(launch_s * 1e6, 1), "launches_timed": prs["pass_launches"], "updates_per_launch": upd,
-                    "per_update_us": round(launch_s * 1e6 / upd, 3), "passes_per_update": round(ppu, 3),
-                    "bound_note": ("fp64 vector issue: the kernel runs one wave per SIMD (a thread owns the whole register file), where "
-                                   "tools/fma_probe reaches 62.5 of the 78.6 TFLOP/s; the rest of the distance is the exchange latency "
-                                   "(`latency`) and instructions that are not flops (register moves between the AGPR-resident weights "
-                                   "and the ALU, reciprocal refinements, code decode).  HBM is far from binding (`hbm`)."),
-                    "hbm": {
-                        "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                        "achieved": None if traffic is None else round(traffic * upd / launch_s / 1e9, 1),
-                        "frac": None if traffic is None else round(traffic * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),
-                        "traffic_bytes_per_update": traffic,
-                        "moved_bytes_per_update": moved, "moved_GBps": round(moved * upd / launch_s / 1e9, 1),
-                        "moved_frac": round(moved * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),
-                        "note": ("achieved / frac: FETCH_SIZE x 2 + WRITE_SIZE of a profiled launch (profiles/pass_kernel_pmc.json) over "
-                                 "this run's launch time; moved_*: the bytes the kernel must move by construction (streamed gamma "
-                                 "read + write, c_n, one 2-bit column)"),
-                    },
-                    "algorithmic_bandwidth_equiv": {
-                        "bytes_per_update": alg_bytes / upd, "GBps": round(alg_bytes / launch_s / 1e9, 1),
-                        "note": ("SURVEY 8(d) bytes of the reference's dataflow (every pass re-reads the N x K weights) over this kernel's "
-                                 "time: a speed-up figure against a memory-bound implementation, not a fraction of any peak -- the "
-                                 "kernel does not move these bytes"),
-                    },
-                    "latency": {
-                        "exchanges_per_update": round(ppu, 3),
-                        "exchange_us_per_update": xus,
-                        "frac_of_update": None if xus is None else round(xus / (launch_s * 1e6 / upd), 4),
-                        "source": rec.get("exchange_source", "no in-kernel timer record for this N, K"),
-                    },
-                    "launch_per_snp": per_snp,
-                    "first_pass": None if per_snp is None else per_snp["first_pass"],
-                    "probe_read_us": None if read_us is None else round(read_us, 3),
-                }
-        else:
-            roofline = per_snp
+          # the kernels of the launch-per-SNP / launch-per-pass sequence (the default mode for K > 8, sharded runs and
+          # shards beyond ~1M individuals; with the whole-schedule kernel they are timed in LAUNCH_PER_SNP mode, switched
+          # to for this measurement only)
+          per_snp = None
+          if mode == "schedule":
+              # (a sharded context has no launch-per-SNP mode: its other sequence is one launch per pass)
+              sub = ts.LAUNCH_PER_SNP if world == 1 else ts.LAUNCH_PER_PASS
+              eng.set_launch_mode(sub)
+              try:
+                  pr, _ = profiled(min(args.steps, 300))
+              finally:
+                  eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+              sub_mode = "snp" if (world == 1 and eng.cfg.max_inner > 2) else "pass"
+          else:
+              pr, _ = profiled(min(args.steps, 300))
+              sub_mode = mode
+          if pr["pass_launches"] and pr["first_launches"]:
+              resident = sub_mode == "snp"
+              rec = pmc_record(sub_mode)
+              first_s = pr["first_ms"] / pr["first_launches"] * 1e-3
+              first_achieved = first_bytes / first_s / 1e9
+              passes_per_launch = pr["pass_launches"] / pr["first_launches"] if resident else 1.0
+              launches = pr["first_launches"] if resident else pr["pass_launches"]
+              avg_s = pr["pass_ms"] / launches * 1e-3
+              alg_bytes = passes_per_launch * pass_bytes
+              equiv = None
+              if resident:
+                  # the resident kernel reads the weights from memory ONCE per SNP and runs the later passes from registers:
+                  # its memory roofline is what it must move (weights once, one column), not passes x the plain-pass bytes
+                  equiv = {"bytes_per_launch": alg_bytes, "GBps": round(alg_bytes / avg_s / 1e9, 1),
+                           "note": "passes x (8NK + N/4), the reference's dataflow, over this kernel's time: not a fraction of any peak"}
+                  alg_bytes = pass_bytes
+                  kernel = (f"ts_resident<{k}> (all {passes_per_launch:.3g} plain passes of a SNP in one launch: weights read once, "
+                            "kept in registers; partial rows exchanged inside the launch)")
+                  note = ("achieved = the bytes the kernel must move per launch (the N x K weights once + one 2-bit column) over its "
+                          "launch time; `traffic` is the counter figure.  It is bound by neither memory nor arithmetic but by the "
+                          "in-launch exchange (about 3 us per pass with the ALU idle) plus the fp64 sweeps (2.6 us per pass at N = 1M, "
+                          "K = 8): per_pass_us x passes = avg_launch_us.  probe_read_us is a bare streaming read of the weights on this "
+                          "box (tsamd_probe_stream).")
+              else:
+                  kernel = f"ts_pass<{k},false> (plain pass, max_inner - 1 launches per update)"
+                  note = ("fabric-side bandwidth incl. Infinity Cache, not DRAM bandwidth: the pass re-reads the same weights (8NK "
+                          "bytes: 64 MB at N=1M, K=8) every launch and they stay in the 256 MiB Infinity Cache; FETCH_SIZE counts "
+                          "those hits.  probe_read_us is a bare streaming read of the same array with the same geometry on this "
+                          "box (tsamd_probe_stream): the second denominator.")
+              achieved = alg_bytes / avg_s / 1e9
+              per_snp = {
+                  "bound": "hbm", "kernel": kernel,
+                  "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("hbm_bytes_per_launch"),
+                  "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bandwidth_equiv": equiv,
+                  "avg_launch_us": round(avg_s * 1e6, 3), "launches_timed": launches,
+                  "passes_per_launch": round(passes_per_launch, 3),
+                  "per_pass_us": round(avg_s * 1e6 / passes_per_launch, 3),
+                  "ceiling_note": note,
+                  "probe_read_us": None if read_us is None else round(read_us, 3),
+                  "frac_of_probe": None if read_us is None else round(read_us * 1e-6 / avg_s, 4),
+                  "first_pass": {
+                      "kernel": f"ts_pass<{k},true> (first pass of a SNP + the previous SNP's gamma step, 1 launch per update)",
+                      "bound": "hbm", "achieved": round(first_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(first_achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("first_pass_hbm_bytes_per_launch"),
+                      "algorithmic_bytes_per_launch": first_bytes, "avg_launch_us": round(first_s * 1e6, 3),
+                      "launches_timed": pr["first_launches"],
+                      "probe_rmw_us": None if rmw_us is None else round(rmw_us, 3),
+                      "frac_of_probe": None if rmw_us is None else round(rmw_us * 1e-6 / first_s, 4),
+                  },
+              }
+          if mode == "schedule":
+              # the dominant (only) kernel of the timed region: ONE launch runs the whole schedule.
+              nsteps = min(args.steps, 2000)
+              prs, ran = profiled(nsteps)
+              if prs["pass_launches"]:
+                  rec = pmc_record("schedule")
+                  launch_s = prs["pass_ms"] / prs["pass_launches"] * 1e-3
+                  upd = nsteps / prs["pass_launches"]
+                  ppu = ran / nsteps                                   # passes per update
+                  # (1) what binds it: fp64 vector arithmetic at one wave per SIMD.  Flops per update from the SQ counters of
+                  # a profiled launch when a record for this (N, K) is committed (profiles/pass_kernel_pmc.json, built from
+                  # rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64), else the hand count of the kernel's own
+                  # formulation (FMA = 2): a sweep is 8K + 20 per individual (two K-term normalisers, two reciprocals, 2K
+                  # accumulations per parent), the gamma step 124K + 30 (normalisers 4K, update 12K, exp(psi) 108K).
+                  hand = ppu * sc * (8.0 * k + 20.0) + sc * (124.0 * k + 30.0)
+                  flops = rec.get("fp64_flops_per_update")
+                  flops_src = "hand count of the kernel's formulation (no counter record for this N, K in profiles/pass_kernel_pmc.json)"
+                  if flops:
+                      flops_src = "SQ_INSTS_VALU_*_F64 counters of a profiled launch: " + ", ".join(rec.get("flops_source_files", []))
+                  else:
+                      flops = hand
+                  tflops = flops * upd / launch_s / 1e12
+                  # (2) memory: what the kernel itself must move per update -- gamma and c_n, read and written, of the items
+                  # whose gamma is not kept in LDS, one 2-bit column -- and what the counters saw
+                  vec, items, n_lds = resident_geometry(k)
+                  moved = (16.0 * sc * k + 8.0 * sc) * (items - n_lds) / items + sc / 4.0
+                  traffic = rec.get("hbm_bytes_per_update")
+                  # (3) the reference's dataflow (SURVEY 8d): per update one first pass 32NK + 8N + N/2 and passes - 1 plain
+                  # passes 8NK + N/4 -- what this kernel would have to move if the weights did not stay in registers
+                  alg_bytes = (nsteps * first_bytes + max(0, ran - nsteps) * pass_bytes) / prs["pass_launches"]
+                  # (4) latency: the in-launch exchanges, during which the vector ALU idles (in-kernel timers of the
+                  # diagnostic build -DTSAMD_SCHED_TIME, recorded with the counters)
+                  xus = rec.get("exchange_us_per_update")
+                  roofline = {
+                      "bound": "fp64_valu",
+                      "kernel": (f"ts_schedule<{k}> (one launch = {upd:.0f} SNP updates: the gamma step and all {ppu:.3g} passes of every "
+                                 "SNP; weights in registers from the first SNP to the last; partial rows exchanged inside the launch)"),
+                      "achieved": round(tflops, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4),
+                      "traffic": None if traffic is None else traffic * upd,
+                      "flops_per_update": flops, "flops_per_update_hand_count": hand, "flops_source": flops_src,
+                      "avg_launch_us": round(launch_s * 1e6, 1), "launches_timed": prs["pass_launches"], "updates_per_launch": upd,
+                      "per_update_us": round(launch_s * 1e6 / upd, 3), "passes_per_update": round(ppu, 3),
+                      "bound_note": ("fp64 vector issue: the kernel runs one wave per SIMD (a thread owns the whole register file), where "
+                                     "tools/fma_probe reaches 62.5 of the 78.6 TFLOP/s; the rest of the distance is the exchange latency "
+                                     "(`latency`) and instructions that are not flops (register moves between the AGPR-resident weights "
+                                     "and the ALU, reciprocal refinements, code decode).  HBM is far from binding (`hbm`)."),
+                      "hbm": {
+                          "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                          "achieved": None if traffic is None else round(traffic * upd / launch_s / 1e9, 1),
+                          "frac": None if traffic is None else round(traffic * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                          "traffic_bytes_per_update": traffic,
+                          "moved_bytes_per_update": moved, "moved_GBps": round(moved * upd / launch_s / 1e9, 1),
+                          "moved_frac": round(moved * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                          "note": ("achieved / frac: FETCH_SIZE x 2 + WRITE_SIZE of a profiled launch (profiles/pass_kernel_pmc.json) over "
+                                   "this run's launch time; moved_*: the bytes the kernel must move by construction (streamed gamma "
+                                   "read + write, c_n, one 2-bit column)"),
+                      },
+                      "algorithmic_bandwidth_equiv": {
+                          "bytes_per_update": alg_bytes / upd, "GBps": round(alg_bytes / launch_s / 1e9, 1),
+                          "note": ("SURVEY 8(d) bytes of the reference's dataflow (every pass re-reads the N x K weights) over this kernel's "
+                                   "time: a speed-up figure against a memory-bound implementation, not a fraction of any peak -- the "
+                                   "kernel does not move these bytes"),
+                      },
+                      "latency": {
+                          "exchanges_per_update": round(ppu, 3),
+                          "exchange_us_per_update": xus,
+                          "frac_of_update": None if xus is None else round(xus / (launch_s * 1e6 / upd), 4),
+                          "source": rec.get("exchange_source", "no in-kernel timer record for this N, K"),
+                      },
+                      "launch_per_snp": per_snp,
+                      "first_pass": None if per_snp is None else per_snp["first_pass"],
+                      "probe_read_us": None if read_us is None else round(read_us, 3),
+                  }
+          else:
+              roofline = per_snp
+      except Exception as exc:  # noqa: BLE001 -- the measured value must still be reported (e.g. a peer timed out in a profiling leg)
+        roofline = None
+        print(f"[bench] roofline legs failed, reported without them: {exc}", file=sys.stderr, flush=True)
 
     # third denominator (SURVEY 8d): what a plain device-to-device copy reaches on this box,
     # with the benchmark's data still resident (read + write bytes over the copy time)

@@ -39,6 +39,8 @@ constexpr int resident_capacity(int k) { return resident_items(k) * resident_vec
 //            (blockIdx < 8) re-reads them until every tag matches, adds them in member order, publishes sums(g);
 //   level 2: every workgroup re-reads the 8 group rows and adds them in group order (sharded: world x 8 rows in its
 //            own rank's Xchg::res_sums, written by the leaders of all ranks over xGMI).
+// Up to kResOneLevelGrid workgroups on one GPU (small shards; 16 in ts_resident) there is only ONE level: every workgroup
+// sweeps every row.  The layouts of the two forms overlap, which is harmless: an exchange is self-contained (tags never repeat).
 // A row is cut into column blocks of 32 granules (16 values); wave w of a workgroup sweeps blocks w, w + 4, ...: one
 // wave at K <= 8, two at K <= 16, four at K <= 32 -- the sweeps of a wide row run side by side on the four SIMDs.
 // An exchange can carry TWO rows (regions A and B): B is the row of a SNP's LAST pass, deferred into the first
@@ -48,6 +50,7 @@ constexpr int resident_capacity(int k) { return resident_items(k) * resident_vec
 // into a no-op until the host has dealt with it (tsamd_synchronize).
 constexpr int kResGroups = 8;    // (Xchg::res_sums is laid out for these two)
 constexpr int kResMembers = 32;  // workgroups per group (grid <= 256)
+constexpr int kResOneLevelGrid = 64;  // up to this many workgroups (one GPU) the exchange has ONE level: everybody reads every row
 constexpr int res_blocks(int k) { return (4 * k + 31) / 32; }  // 32-granule column blocks of a row of 2K values
 constexpr int kResMaxGran = 32 * res_blocks(kResidentMaxK);
 constexpr int kResRegionRows = kResGroups * kResMembers + 2 * kResGroups;  // member rows, then two slots of group sums
@@ -65,6 +68,10 @@ struct ResLay {
   }
   static __device__ __forceinline__ unsigned long long *sums(ResXchg *xb, uint32_t region, uint32_t slot, uint32_t g) {
     return xb->gran + region * kRegion + ((uint32_t)(kResGroups * kResMembers) + slot * (uint32_t)kResGroups + g) * GR;
+  }
+  // one level (grid <= kResOneLevelGrid): row `row` of slot `slot`, laid over the member rows
+  static __device__ __forceinline__ unsigned long long *flat(ResXchg *xb, uint32_t region, uint32_t slot, uint32_t row) {
+    return xb->gran + region * kRegion + (slot * (uint32_t)kResOneLevelGrid + row) * GR;
   }
   // sharded: level 2 in Xchg::res_sums of every rank, row r * 8 + g of (slot, region)
   static __device__ __forceinline__ unsigned long long *rank_sums(Xchg *x, uint32_t region, uint32_t slot, uint32_t row) {
@@ -142,7 +149,7 @@ __device__ __forceinline__ void res_post(unsigned long long *dst, uint32_t tag, 
 // region-A row in `mine`; with width == 2 thread 64 + j brings value j of the region-B row.  On return (after a
 // workgroup barrier) s_tot[0][j] holds the region-A totals in every workgroup and s_tot[1][j] the region-B totals in
 // workgroup 0.  WR: row pairs per lane of the cross-rank level 2 (0: one GPU).  false: a bounded wait gave up.
-template <int KT, int WR>
+template <int KT, int WR, int ONE = kResOneLevelGrid>
 __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, uint32_t tag, uint32_t width, double mine, uint32_t g, uint32_t m,
                                              uint32_t grid, double *s_tot /* [2][2K] */, int *s_alive /* [4], all 1 */, uint32_t tid,
                                              unsigned long long code, unsigned long long ticks) {
@@ -150,11 +157,48 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
   constexpr uint32_t J = 2 * KT, RB = (uint32_t)res_blocks(KT), GR = L::GR;
   constexpr int kPerWave = (2 * (int)RB + 3) / 4;  // column blocks a wave sweeps at most
   const uint32_t lane = tid & 63u, wave = tid >> 6;
+  const uint32_t nblk = width * RB;
+  if constexpr (WR == 0 && ONE > 0) {
+    if (grid <= (uint32_t)ONE) {
+      // Few workgroups (shards up to ~16K individuals: the sizes of real cohorts): ONE level.  Every workgroup posts its
+      // row(s) into slot tag & 1 of a flat array (row = blockIdx) and sweeps all rows itself, adding them in workgroup
+      // order: one store -> visible -> load chain instead of two.  Two slots: nobody can post exchange x + 2 before
+      // everybody has posted x + 1, i.e. has finished reading x.
+      const uint32_t slot = tag & 1u;
+      {
+        const uint32_t region = tid >> 6, j = tid & 63u;
+        if (region < width && j < J) res_post(L::flat(xb, region, slot, blockIdx.x) + 2u * j, tag, mine, 0);
+      }
+      bool alive1 = true;
+#pragma unroll
+      for (int u = 0; u < kPerWave; ++u) {
+        const uint32_t q = wave + 4u * (uint32_t)u;
+        if (q < nblk && (q < RB || blockIdx.x == 0)) {
+          const uint32_t region = q / RB, cb = q % RB, nvalid = min(32u, 2u * J - 32u * cb);
+          double s = 0.0;
+          if (ONE <= 16 || grid <= 16u) {
+            unsigned v[8];
+            alive1 = res_sweep<8, __HIP_MEMORY_SCOPE_AGENT>(L::flat(xb, region, slot, 0), GR, 32u * cb, tag, nvalid, grid, v, &xb->abort_word, p.host_error,
+                                                            code, ticks, lane) && alive1;
+            s = res_sum<8>(v, lane);
+          } else if constexpr (ONE > 16) {
+            unsigned v[ONE / 2];
+            alive1 = res_sweep<ONE / 2, __HIP_MEMORY_SCOPE_AGENT>(L::flat(xb, region, slot, 0), GR, 32u * cb, tag, nvalid, grid, v, &xb->abort_word,
+                                                                  p.host_error, code, ticks, lane) && alive1;
+            s = res_sum<ONE / 2>(v, lane);
+          }
+          if (lane < nvalid && !(lane & 1u)) s_tot[region * J + 16u * cb + (lane >> 1)] = s;
+        }
+      }
+      if (lane == 0 && !alive1) s_alive[wave] = 0;
+      __syncthreads();
+      return (s_alive[0] & s_alive[1] & s_alive[2] & s_alive[3]) != 0;
+    }
+  }
   {
     const uint32_t region = tid >> 6, j = tid & 63u;
     if (region < width && j < J) res_post(L::rows(xb, region, g, m) + 2u * j, tag, mine, 0);
   }
-  const uint32_t nblk = width * RB;
   const uint32_t members = g < grid ? (grid - g + (uint32_t)kResGroups - 1u) / (uint32_t)kResGroups : 0u;
   const uint32_t groups = min(grid, (uint32_t)kResGroups);
   bool alive = true;
@@ -316,7 +360,7 @@ template <int KT>
 __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partials_a, double *w_a, uint32_t npad_a, uint32_t chunk_a,
                                                       uint32_t par_arg, uint32_t nrows_hint, ResXchg *xb, uint32_t serial, const DevParams p) {
   constexpr int BLOCK = 256, kWaves = BLOCK / 64, VEC = resident_vec(KT), kItems = resident_items(KT);
-  constexpr bool BS = KT <= 24, BSC = KT <= 8;  // exp(Elogbeta) of a pass in registers / in scalar registers
+  constexpr bool BS = KT <= 12, BSC = KT <= 8;  // (vector registers only up to K = 12 here: this kernel also holds the first sweep's loads in flight)
   using LN = Lanes<VEC>;
   using WT = typename LN::T;
   using RC = ResCodes<VEC>;
@@ -447,7 +491,8 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
     xcount += 1u;
     const uint32_t tag = xseq0 + xcount;
     // (nothing has been written to memory before the launch's first exchange: a failure there leaves the state intact)
-    if (!res_exchange<KT, 0>(xb, p, tag, 1u, row, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, xcount == 1u, par, serial),
+    // (one level only up to 16 workgroups here, and only at K <= 8: the sweep's registers do not fit beside this kernel's)
+    if (!res_exchange<KT, 0, (KT <= 8 ? 16 : 0)>(xb, p, tag, 1u, row, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, xcount == 1u, par, serial),
                              xcount == 1u ? (unsigned long long)p.probe_ticks : kResWaitTicks))
       return true;  // (the abort word is set: tsamd_synchronize deals with it)
     if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);

@@ -23,10 +23,25 @@ def init_process_group(backend="gloo"):
 
 
 def bootstrap_comm(engine, dist):
-    """rank 0 makes the RCCL unique id, every rank joins the communicator."""
-    uid = [engine.comm_unique_id() if dist.get_rank() == 0 else None]
+    """rank 0 makes the RCCL unique id, every rank joins the communicator.
+    Raises on EVERY rank if any rank failed, so callers can fall back together."""
+    err = None
+    uid = [None]
+    if dist.get_rank() == 0:
+        try:
+            uid = [engine.comm_unique_id()]
+        except Exception as exc:  # noqa: BLE001
+            err = exc
     dist.broadcast_object_list(uid, src=0)
-    engine.comm_init(uid[0])
+    if uid[0] is not None:
+        try:
+            engine.comm_init(uid[0])
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+    elif err is None:
+        err = RuntimeError("rank 0 could not create the RCCL unique id")
+    if not all_ok(err is None, dist):
+        raise RuntimeError(f"RCCL communicator unavailable: {err or 'a peer failed'}")
 
 
 def all_ok(ok, dist):

@@ -156,3 +156,113 @@ def test_in_launch_exchange_order_gives_every_rank_the_same_bits(tmp_path):
         assert rel_err(o["lam"], ref.lambda_()) < 1e-11
         assert rel_err(o["gamma"], ref.gamma()) < 1e-10
     assert np.array_equal(outs[0]["lam"], outs[1]["lam"])
+
+
+# ---- bench.py's exchange self-test (N > 1): its control flow on CPU ---------------------------------------------
+class _FakeTs:
+    """Stand-in for the terastructure_amd module: engines whose arithmetic is the oracle's (ShardedOracle above) and whose
+    failures are scripted, so that choose_exchange's collective sequence can be exercised without a GPU."""
+    LAUNCH_PER_PASS = 0
+
+    def __init__(self, shard_range, gamma_full, fail_mode, fail_rank):
+        self.shard_range, self.gamma_full, self.fail_mode, self.fail_rank = shard_range, gamma_full, fail_mode, fail_rank
+        self.created = 0
+        ts = self
+
+        class Engine:
+            def __init__(self, n, l, k, device=0, rank=0, world=1):
+                ts.created += 1
+                self.n, self.l, self.k, self.rank, self.world = n, l, k, rank, world
+                # candidates are created in the order rccl, p2p, p2p_schedule, p2p_schedule3
+                self.mode = ["rccl", "p2p", "p2p_schedule", "p2p_schedule3"][ts.created - 1]
+                self.fail_now = False
+
+            def synth_genotypes(self, theta_shard, beta, seed=1):
+                y, _, _ = psd_genotypes(self.n, self.l, self.k, seed, 0.02)
+                self.payload = pack_bed(y)
+
+            def set_gamma(self, rows):
+                self.sh = ShardedOracle(self.n, self.l, self.k, self.payload, ts.gamma_full, self.rank, self.world, ts.shard_range)
+
+            def comm_unique_id(self):
+                raise RuntimeError("no RCCL on the CPU box")
+
+            def comm_init(self, uid):
+                raise RuntimeError("no RCCL on the CPU box")
+
+            def p2p_export(self):
+                return b"h" * 64
+
+            def p2p_connect(self, handles):
+                assert len(handles) == self.world
+
+            def launch_info(self):
+                return {"kernels_per_snp": 0}
+
+            def set_launch_mode(self, mode):
+                pass
+
+            def download_bed(self, j):
+                b, c = self.sh.b, self.sh.c
+                return self.payload[j, b // 4:(b + c + 3) // 4]
+
+            def run_schedule(self, locs, hol_mode=0):
+                for loc in locs:
+                    self.sh.snp_update(int(loc), hol_mode)   # (collective inside: every rank gets here)
+                self.fail_now = self.mode == ts.fail_mode and self.rank == ts.fail_rank
+
+            def synchronize(self):
+                if self.fail_now:                             # ... and ONE rank reports a failure afterwards, like a
+                    raise RuntimeError("tsamd error -4: scripted timeout")   # bounded in-kernel wait that gave up
+
+            def get_lambda(self):
+                return self.sh.orc.lambda_()
+
+            def get_gamma(self):
+                return self.sh.orc.gamma()[self.sh.b:self.sh.b + self.sh.c]
+
+            def get_counts(self):
+                return self.sh.orc.c_indiv()[self.sh.b:self.sh.b + self.sh.c]
+
+            def close(self):
+                self.sh.orc.close()
+
+        self.Engine = Engine
+
+
+def _selftest_worker(rank, world, port, n, k, fail_mode, fail_rank, out_dir):
+    import datetime
+    import sys
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import terastructure_amd as ts
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    gamma_full = init_gamma(n, k, 5)
+    fake = _FakeTs(ts.shard_range, gamma_full, fail_mode, fail_rank)
+    fake.shard_range = ts.shard_range
+    sb, sc = ts.shard_range(n, rank, world)
+    chosen, report = bench.choose_exchange(fake, dist, rank, world, 0, n, k, None, gamma_full, (sb, sc), 2)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([str(chosen), str(sorted(report["valid"].items()))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_mode,fail_rank", [("p2p", 1), ("p2p_schedule", 0), (None, 0)])
+def test_exchange_selftest_keeps_ranks_aligned_when_one_rank_fails(tmp_path, fail_mode, fail_rank):
+    """bench.py's start-up self-test of the exchanges (N > 1), world = 2 on CPU with engines whose arithmetic is the
+    oracle's: a candidate whose run fails on ONE rank only is marked invalid on every rank and nobody is left waiting in a
+    collective the failing rank skipped (a 4-rank rehearsal once hung for gloo's 30 minutes that way); the remaining
+    candidates are checked against the oracle and one of them is chosen -- the same one on every rank."""
+    world, n, k = 2, 1003, 5
+    port = _free_port()
+    mp.spawn(_selftest_worker, args=(world, port, n, k, fail_mode, fail_rank, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(os.path.join(tmp_path, f"r{r}.npy")) for r in range(world)]
+    assert list(outs[0]) == list(outs[1])                      # same verdict everywhere
+    chosen, valid = outs[0][0], dict(eval(outs[0][1]))
+    assert valid["rccl"] is False
+    for m in ("p2p", "p2p_schedule", "p2p_schedule3"):
+        assert valid[m] is (m != fail_mode), (m, valid)
+    assert chosen in [m for m in ("p2p", "p2p_schedule", "p2p_schedule3") if m != fail_mode]

@@ -140,13 +140,14 @@ def test_modes_a_context_does_not_qualify_for(ts):
             eng.set_launch_mode(7)
 
 
+@pytest.mark.parametrize("n", [30_000, 6_000])      # 118 workgroups: two-level exchange; 24: one level (every workgroup reads every row)
 @pytest.mark.parametrize("k", [8, 12, 20])
-def test_deferred_last_exchange_patterns(ts, k):
+def test_deferred_last_exchange_patterns(ts, k, n):
     """ts_schedule parks the row of a SNP's last pass (under the pass cap) for the next SNP's first exchange unless the
     next or the next-but-one SNP is at the same location, the launch ends, or the SNP stopped early.  Every such
     neighbourhood, with a pass cap of 2 (the deferred pass directly follows the first) and of 10, with converging SNPs
     mixed in, cut into launches at every position: against the oracle and bitwise against uncut."""
-    n, l = 30_000, 6
+    l = 6
     locs = np.array([0, 1, 2, 0, 0, 3, 4, 3, 5, 5, 5, 1, 2, 1, 0, 4, 4, 2, 3, 3, 1, 5, 0, 2], dtype=np.uint32)
     for max_inner, thresh in ((10, None), (2, None), (10, 6.0), (3, 2.0)):
         over = {} if thresh is None else {"conv_thresh": thresh}
