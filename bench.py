@@ -438,7 +438,7 @@ def main():
     roofline = None
     if not args.no_profile:
       try:
-        info = eng.launch_info()
+          info = eng.launch_info()
           kps = info["kernels_per_snp"]
           mode = "schedule" if kps == 0 else "snp" if (kps == 2 and eng.cfg.max_inner > 2) else "pass"
           pass_bytes = 8.0 * sc * k + sc / 4.0

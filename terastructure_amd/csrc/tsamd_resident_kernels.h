@@ -39,8 +39,9 @@ constexpr int resident_capacity(int k) { return resident_items(k) * resident_vec
 //            (blockIdx < 8) re-reads them until every tag matches, adds them in member order, publishes sums(g);
 //   level 2: every workgroup re-reads the 8 group rows and adds them in group order (sharded: world x 8 rows in its
 //            own rank's Xchg::res_sums, written by the leaders of all ranks over xGMI).
-// Up to kResOneLevelGrid workgroups on one GPU (small shards; 16 in ts_resident) there is only ONE level: every workgroup
-// sweeps every row.  The layouts of the two forms overlap, which is harmless: an exchange is self-contained (tags never repeat).
+// Up to kResOneLevelGrid = 16 workgroups on one GPU (shards up to 4 096 individuals: the sizes of real cohorts; K <= 8 only
+// in ts_resident) there is only ONE level: every workgroup sweeps every row.  The layouts of the two forms overlap, which
+// is harmless: an exchange is self-contained (tags never repeat).
 // A row is cut into column blocks of 32 granules (16 values); wave w of a workgroup sweeps blocks w, w + 4, ...: one
 // wave at K <= 8, two at K <= 16, four at K <= 32 -- the sweeps of a wide row run side by side on the four SIMDs.
 // An exchange can carry TWO rows (regions A and B): B is the row of a SNP's LAST pass, deferred into the first
@@ -50,7 +51,10 @@ constexpr int resident_capacity(int k) { return resident_items(k) * resident_vec
 // into a no-op until the host has dealt with it (tsamd_synchronize).
 constexpr int kResGroups = 8;    // (Xchg::res_sums is laid out for these two)
 constexpr int kResMembers = 32;  // workgroups per group (grid <= 256)
-constexpr int kResOneLevelGrid = 64;  // up to this many workgroups (one GPU) the exchange has ONE level: everybody reads every row
+#ifndef TSAMD_ONE_LEVEL  // (experiments: 0 = always two levels; measured: 16 rows 34.5 us per update against 43.8 with two
+#define TSAMD_ONE_LEVEL 16  // levels at N = 1 718 ... 4 096, K = 8; 40 ... 63 rows 46.0 against 43.8: profiles/r03_experiments.md)
+#endif
+constexpr int kResOneLevelGrid = TSAMD_ONE_LEVEL;  // up to this many workgroups (one GPU) the exchange has ONE level: everybody reads every row
 constexpr int res_blocks(int k) { return (4 * k + 31) / 32; }  // 32-granule column blocks of a row of 2K values
 constexpr int kResMaxGran = 32 * res_blocks(kResidentMaxK);
 constexpr int kResRegionRows = kResGroups * kResMembers + 2 * kResGroups;  // member rows, then two slots of group sums
@@ -160,7 +164,7 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
   const uint32_t nblk = width * RB;
   if constexpr (WR == 0 && ONE > 0) {
     if (grid <= (uint32_t)ONE) {
-      // Few workgroups (shards up to ~16K individuals: the sizes of real cohorts): ONE level.  Every workgroup posts its
+      // Few workgroups (shards up to 4 096 individuals: the sizes of real cohorts): ONE level.  Every workgroup posts its
       // row(s) into slot tag & 1 of a flat array (row = blockIdx) and sweeps all rows itself, adding them in workgroup
       // order: one store -> visible -> load chain instead of two.  Two slots: nobody can post exchange x + 2 before
       // everybody has posted x + 1, i.e. has finished reading x.
