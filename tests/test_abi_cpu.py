@@ -82,3 +82,32 @@ def test_no_gpu_fails_loudly(ts):
     # bad config is rejected before any device work
     with pytest.raises(ts.TsamdError):
         ts.Engine(100, 10, 129)
+
+
+def test_resident_geometry_mirrors_agree(tmp_path):
+    """The resident kernels' geometry (individuals per thread, items whose gamma stays in LDS, capacity per GPU) is stated in
+    csrc/tsamd_resident_kernels.h and mirrored by bench.py (bytes the kernel must move) and include/tsamd.h (capacity
+    table): compile the header's constexpr functions for the host and compare."""
+    import sys
+
+    src = tmp_path / "geom.hip"
+    src.write_text('#include <cstdio>\n#include "tsamd_resident_kernels.h"\nint main() {\n'
+                   '  for (int k = 1; k <= 32; ++k)\n'
+                   '    printf("%d %d %d %d %d\\n", k, tsamd::resident_vec(k), tsamd::resident_items(k),\n'
+                   '           tsamd::sched_lds_items(k, tsamd::resident_items(k), tsamd::resident_vec(k)), tsamd::resident_capacity(k));\n'
+                   '  return 0;\n}\n')
+    exe = tmp_path / "geom"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "terastructure_amd", "csrc"), str(src), "-o", str(exe)])
+    rows = [tuple(int(x) for x in ln.split()) for ln in subprocess.check_output([str(exe)], text=True).splitlines()]
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for k, vec, items, lds, cap in rows:
+        assert bench.resident_geometry(k) == (vec, items, lds), k
+        assert cap == 256 * items * vec and 0 < lds <= items
+        assert items * k <= 128                                     # at most 256 registers of weights per thread
+    by_k = {r[0]: r for r in rows}
+    # the capacity table of include/tsamd.h (tsamd_launch_info) and DESIGN.md section 4
+    assert by_k[8][4] * 256 == 1_048_576 and by_k[16][4] * 256 == 524_288 and by_k[20][4] * 256 == 327_680
+    assert by_k[24][4] * 256 == 262_144 and by_k[32][4] * 256 == 196_608 and by_k[9][4] * 256 == 917_504

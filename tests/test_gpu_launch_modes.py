@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import oracle_py as op
-from helpers import init_gamma, pack_bed, psd_genotypes, rel_err
+from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, usable_cores
 from test_gpu_parity import assert_state_close, ts  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -28,7 +28,7 @@ def make(ts, n, l, k, seed, **cfg):
     eng.upload_bed(payload)
     eng.set_gamma(g)
     ocfg = {"online_iterations": cfg["max_inner"]} if "max_inner" in cfg else {}
-    orc = op.Oracle(n, l, k, **ocfg)
+    orc = op.Oracle(n, l, k, nthreads=usable_cores() if n * k > 100_000 else 1, **ocfg)
     orc.load_bed_payload(payload)
     orc.set_gamma(g)
     return eng, orc, payload, g
@@ -154,7 +154,7 @@ def test_deferred_last_exchange_patterns(ts, k, n):
         eng, orc, payload, g = make(ts, n, l, k, 400 + k, max_inner=max_inner, **over)
         if thresh is not None:
             orc.close()
-            orc = op.Oracle(n, l, k, online_iterations=max_inner, meanchangethresh=thresh)
+            orc = op.Oracle(n, l, k, online_iterations=max_inner, meanchangethresh=thresh, nthreads=usable_cores())
             orc.load_bed_payload(payload)
             orc.set_gamma(g)
         with eng:

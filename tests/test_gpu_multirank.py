@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_py as op
-from helpers import init_gamma, pack_bed, psd_genotypes, rel_err
+from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, usable_cores
 
 pytestmark = [pytest.mark.gpu, pytest.mark.spawns]
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -63,7 +63,7 @@ def _run_ranks(tmp_path, mode, world, n, l, k, seed, nsnp, extra_env=None, ok_co
 
 def _oracle_run(n, l, k, seed, nsnp, **over):
     y, _, _ = psd_genotypes(n, l, k, seed, 0.03)
-    orc = op.Oracle(n, l, k, **over)
+    orc = op.Oracle(n, l, k, nthreads=usable_cores() if n * k > 100_000 else 1, **over)
     orc.load_bed_payload(pack_bed(y))
     orc.set_gamma(init_gamma(n, k, seed + 1))
     rng = np.random.default_rng(seed + 2)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle_py as op
-from helpers import init_gamma, pack_bed, psd_genotypes
+from helpers import init_gamma, pack_bed, psd_genotypes, usable_cores
 from test_gpu_parity import assert_state_close, ts  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +32,7 @@ def test_launch_that_cannot_be_resident_is_replayed(ts, mode_name, n, k, monkeyp
     payload = pack_bed(y)
     g = init_gamma(n, k, 56)
     del y
-    orc = op.Oracle(n, l, k)
+    orc = op.Oracle(n, l, k, nthreads=usable_cores())
     orc.load_bed_payload(payload)
     orc.set_gamma(g)
     with ts.Engine(n, l, k) as eng:
@@ -75,7 +75,7 @@ def test_single_updates_survive_a_tenant(ts, monkeypatch):
     payload = pack_bed(y)
     g = init_gamma(n, k, 9)
     del y
-    orc = op.Oracle(n, l, k)
+    orc = op.Oracle(n, l, k, nthreads=usable_cores())
     orc.load_bed_payload(payload)
     orc.set_gamma(g)
     with ts.Engine(n, l, k) as eng:
