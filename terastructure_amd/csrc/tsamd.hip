@@ -1221,12 +1221,18 @@ static int enqueue_entries(tsamd_ctx *c, const uint32_t *ent, uint32_t n, bool e
 // from the journal, what the failed launch and everything enqueued after it were to do.  The reference never loses
 // the model to a scheduling hiccup either (it traps SIGTERM to save it, src/snpsamplinge.cc:454-457).
 static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
-  const uint32_t serial = (uint32_t)(code >> 34), par = (uint32_t)(code >> 33) & 1u;
+  // (the error word carries the low 30 bits of the launch serial: compare modulo 2^30)
+  constexpr uint32_t kSerialMask = (1u << 30) - 1u;
+  const uint32_t serial = (uint32_t)(code >> 34) & kSerialMask, par = (uint32_t)(code >> 33) & 1u;
   size_t at = c->journal.size();
+  uint32_t ahead = 0;  // launches of the failed schedule before the failed one
   for (size_t i = 0; i < c->journal.size(); ++i) {
     const tsamd_ctx::Journal &j = c->journal[i];
     const uint32_t launches = j.mode == 2 ? (j.n + kScheduleChunk - 1u) / kScheduleChunk : j.mode == 1 ? j.n : 0u;
-    if (serial - j.serial0 < launches) at = i;
+    if (((serial - j.serial0) & kSerialMask) < launches) {
+      at = i;
+      ahead = (serial - j.serial0) & kSerialMask;
+    }
   }
   if (at == c->journal.size())
     return fail(c, TSAMD_EHIP, "a resident launch (serial %u) gave up at its entry but is not in the journal of %zu schedule(s)", serial,
@@ -1242,7 +1248,7 @@ static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
   {
     const tsamd_ctx::Journal &j = c->journal[at];
     if (was_persistent) {
-      const uint32_t off = (serial - j.serial0) * kScheduleChunk;
+      const uint32_t off = ahead * kScheduleChunk;
       rc = enqueue_entries(c, j.ent + off, j.n - off, true);
     } else {
       // ts_resident of SNP st.idx of this schedule: its first pass is done and pending (rows in the same slot); run its
