@@ -434,14 +434,24 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
 // Launch geometry of the resident kernels for a shard of `npad` padded individuals on at most `cap` workgroups (all
 // resident at once): items of resident_vec(K) individuals, a whole number of 256-thread rounds per workgroup.  False
 // when the shard does not fit resident_items(K) items per thread.
-bool resident_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, uint32_t *chunk) {
+bool resident_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, uint32_t *chunk, bool one_gpu = false) {
   if (cap == 0u || (int)k > kResidentMaxK) return false;
   const uint32_t nitems = npad / (uint32_t)resident_vec((int)k);
-  uint32_t ch = (nitems + cap - 1u) / cap;
-  ch = (ch + (uint32_t)kResidentBlock - 1u) / (uint32_t)kResidentBlock * (uint32_t)kResidentBlock;
-  if (ch > (uint32_t)(resident_items((int)k) * kResidentBlock)) return false;
-  *chunk = ch;
-  *grid = (nitems + ch - 1u) / ch;
+  auto rounds = [&](uint32_t workgroups) {
+    const uint32_t ch = (nitems + workgroups - 1u) / workgroups;
+    return (ch + (uint32_t)kResidentBlock - 1u) / (uint32_t)kResidentBlock;
+  };
+  uint32_t r = rounds(cap);
+  if (r > (uint32_t)resident_items((int)k)) return false;
+  // Small shards on one GPU: up to kResOneLevelGrid workgroups exchange in ONE level (1.9 us against 3.0 per pass), which is
+  // worth a few more individuals per thread -- each costs about 0.33 K us per update (gamma step + ten sweeps), the nine
+  // shorter exchanges save about 10 (profiles/r03_experiments.md)
+  if (one_gpu && kResOneLevelGrid > 0 && (nitems + r * (uint32_t)kResidentBlock - 1u) / (r * (uint32_t)kResidentBlock) > (uint32_t)kResOneLevelGrid) {
+    const uint32_t r1 = rounds((uint32_t)kResOneLevelGrid);
+    if (r1 <= (uint32_t)resident_items((int)k) && (r1 - r) * k < 20u) r = r1;  // (measured: K = 8, N = 10 000: 39.0 against 43.7 us per update; K = 20, N = 8 000 would lose)
+  }
+  *chunk = r * (uint32_t)kResidentBlock;
+  *grid = (nitems + *chunk - 1u) / *chunk;
   return true;
 }
 
@@ -727,7 +737,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
     // (TSAMD_GRID / TSAMD_BLOCK shape the launch-per-pass kernels: a context they are set for runs those)
     const bool fits = !c->wide && cus > 0 && env_u32("TSAMD_GRID", 0) == 0u &&
                       resident_geometry(cfg->k, c->npad, std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)cus), &c->sched_grid,
-                                        &c->sched_chunk);
+                                        &c->sched_chunk, cfg->world == 1u);
     c->resident = fits && !c->split && cfg->world == 1 && cfg->max_inner >= 2 && cfg->max_inner <= 200 &&
                   env_u32("TSAMD_RESIDENT", 1) != 0u && kResidentBlocksPerCu[cfg->k]() >= 1;
     // ... and then, with the reference's default learning-rate exponent (the kernel carries no pow()), the whole
