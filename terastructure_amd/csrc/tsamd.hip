@@ -450,6 +450,12 @@ bool resident_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, 
     const uint32_t r1 = rounds((uint32_t)kResOneLevelGrid);
     if (r1 <= (uint32_t)resident_items((int)k) && (r1 - r) * k < 20u) r = r1;  // (measured: K = 8, N = 10 000: 39.0 against 43.7 us per update; K = 20, N = 8 000 would lose)
   }
+  // ... and the smallest cohorts on ONE workgroup, which exchanges nothing at all (a pass is then a sweep, a fold and an
+  // epilogue: about 1 us), when its extra individuals per thread cost less than the exchanges they replace
+  if (one_gpu) {
+    const uint32_t r0 = rounds(1u);
+    if (r0 <= (uint32_t)resident_items((int)k) && (r0 - r) * k < 50u) r = r0;
+  }
   *chunk = r * (uint32_t)kResidentBlock;
   *grid = (nitems + *chunk - 1u) / *chunk;
   return true;

@@ -39,8 +39,8 @@ constexpr int resident_capacity(int k) { return resident_items(k) * resident_vec
 //            (blockIdx < 8) re-reads them until every tag matches, adds them in member order, publishes sums(g);
 //   level 2: every workgroup re-reads the 8 group rows and adds them in group order (sharded: world x 8 rows in its
 //            own rank's Xchg::res_sums, written by the leaders of all ranks over xGMI).
-// Up to kResOneLevelGrid = 16 workgroups on one GPU (shards up to 4 096 individuals: the sizes of real cohorts; K <= 8 only
-// in ts_resident) there is only ONE level: every workgroup sweeps every row.  The layouts of the two forms overlap, which
+// A single workgroup exchanges nothing.  Up to kResOneLevelGrid = 16 workgroups on one GPU (shards up to 4 096 individuals:
+// the sizes of real cohorts; K <= 8 only in ts_resident) there is only ONE level: every workgroup sweeps every row.  The layouts of the two forms overlap, which
 // is harmless: an exchange is self-contained (tags never repeat).
 // A row is cut into column blocks of 32 granules (16 values); wave w of a workgroup sweeps blocks w, w + 4, ...: one
 // wave at K <= 8, two at K <= 16, four at K <= 32 -- the sweeps of a wide row run side by side on the four SIMDs.
@@ -162,6 +162,14 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
   constexpr int kPerWave = (2 * (int)RB + 3) / 4;  // column blocks a wave sweeps at most
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   const uint32_t nblk = width * RB;
+  if constexpr (WR == 0) {
+    if (grid == 1u) {  // ONE workgroup (the smallest cohorts): its row is the total, nothing goes through memory
+      const uint32_t region = tid >> 6, j = tid & 63u;
+      if (region < width && j < J) s_tot[region * J + j] = mine;
+      __syncthreads();
+      return true;
+    }
+  }
   if constexpr (WR == 0 && ONE > 0) {
     if (grid <= (uint32_t)ONE) {
       // Few workgroups (shards up to 4 096 individuals: the sizes of real cohorts): ONE level.  Every workgroup posts its
