@@ -100,11 +100,11 @@ __device__ __forceinline__ PendingIn load_pending(const State *S, uint32_t J) {
 }
 // The K x 2 epilogue proper, for the thread that holds lt = the row total of value j (threads j and j ^ 1 are
 // neighbouring lanes of one wave): lambda_t = eb_used * lt, update_lambda, estimate_beta; outputs into LDS.
-__device__ __forceinline__ void epilogue_values_at(const DevParams &p, uint32_t j, double lt, double eb_used, double lam_old,
-                                                   double *s_lam, double *s_eb, double *s_diff) {
+__device__ __forceinline__ void epilogue_values_reg(const DevParams &p, uint32_t j, double lt, double eb_used, double lam_old,
+                                                    double &nw, double &eb_new, double &diff) {
   // eta + b[k,t] * (row sum): the b factored out of the accumulation; an explicit fma so that
   // every kernel that inlines this rounds the same way whatever the compiler would contract
-  const double nw = fma(lt, eb_used, (j & 1u) ? p.eta1 : p.eta0);
+  nw = fma(lt, eb_used, (j & 1u) ? p.eta1 : p.eta0);
   // exp(Elogbeta_kt) = exp(psi(lambda_kt) - psi(lambda_k0 + lambda_k1)) without a log: both
   // digammas in the split form z * exp(a) (tsamd_device.h), side by side in one instruction
   // stream; the pair sum comes from the neighbouring lane (t = 0/1 are adjacent threads)
@@ -112,9 +112,16 @@ __device__ __forceinline__ void epilogue_values_at(const DevParams &p, uint32_t 
   double z1, a1, z2, a2;
   exp_digamma_split(nw, z1, a1);
   exp_digamma_split(pair, z2, a2);
+  eb_new = (z1 * fast_rcp(z2)) * exp_nonpos(a1 - a2);
+  diff = fabs(nw - lam_old);
+}
+__device__ __forceinline__ void epilogue_values_at(const DevParams &p, uint32_t j, double lt, double eb_used, double lam_old,
+                                                   double *s_lam, double *s_eb, double *s_diff) {
+  double nw, eb_new, diff;
+  epilogue_values_reg(p, j, lt, eb_used, lam_old, nw, eb_new, diff);
   s_lam[j] = nw;
-  s_eb[j] = (z1 * fast_rcp(z2)) * exp_nonpos(a1 - a2);
-  s_diff[j] = fabs(nw - lam_old);
+  s_eb[j] = eb_new;
+  s_diff[j] = diff;
 }
 // ... called by threads tid < J for value tid
 __device__ __forceinline__ void epilogue_values(const DevParams &p, double lt, double eb_used, double lam_old,

@@ -18,6 +18,9 @@
 #include "tsamd_kernels.h"
 
 namespace tsamd {
+#ifndef TSAMD_NOCOL_K
+#define TSAMD_NOCOL_K 0
+#endif
 
 // ---- geometry per K ---------------------------------------------------------------------------------------------
 constexpr int kResidentMaxK = 32;
@@ -574,7 +577,7 @@ constexpr int sched_lds_items(int k, int items, int vec) {
 #ifdef TSAMD_SCHED_LDS_ITEMS  // (experiments, tools/variant.sh)
   return TSAMD_SCHED_LDS_ITEMS < items ? TSAMD_SCHED_LDS_ITEMS : items;
 #else
-  const int small = 1536 + 18 * 2 * k * 8;  // the K x 2 arrays below
+  const int small = 1536 + 26 * 2 * k * 8;  // the K x 2 arrays below
   const int per_item = (k * 8 + 4) * vec * 256, n = (160 * 1024 - small) / per_item;
   return n < items ? n : items;
 #endif
@@ -600,6 +603,19 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   __shared__ __attribute__((aligned(16))) double s_sb[J];
   __shared__ double s_lam[J], s_diff[J], s_tot[2 * J], s_plam[J], s_peb[J];
   __shared__ double s_drow[J], s_dlam[J], s_dolam[J], s_doeb[J], s_ddiff[J];  // the deferred last pass of the previous SNP
+  // kRepl: every WAVE runs the K x 2 epilogue of a pass for itself on lanes < 2K (same totals, same code, same bits) and
+  // keeps lambda / exp(Elogbeta) of the pending pass in those lanes' registers: no workgroup barrier between the exchange
+  // and the next sweep, nobody waits for wave 0 (-7 % per update below ~250K individuals, where an update IS its
+  // exchanges and epilogues).  exp(Elogbeta) and the |dlambda| terms go through a per-wave LDS row only to be broadcast to
+  // the wave's other lanes.  K <= 8 only; the instantiation without the skip branches (full-size shards) keeps round 2's
+  // shared form -- threads < 2K, shared arrays, a barrier: with the per-wave form it no longer fits the register file.
+#ifdef TSAMD_SHARED_EPILOGUE  // (experiments)
+  constexpr bool kRepl = false;
+#else
+  constexpr bool kRepl = PARTIAL && KT <= 8;  // (K > 8: measured neutral to 1.5 % slower -- wider rows, more lanes in the epilogue)
+#endif
+  __shared__ __attribute__((aligned(16))) double s_ebw[kWaves][J];
+  __shared__ double s_diffw[kWaves][J];
   __shared__ double s_red[kWaves * J];
   __shared__ int s_alive[4];
   // gamma (and c_n) of kLds of a thread's items stay in LDS for the whole launch, spread evenly over the items; the
@@ -756,22 +772,30 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   bool complete = false;
   // every later SNP's column is requested while its predecessor runs -- except at K = 16, whose 128 resident doubles
   // per thread leave no room for the words in flight (36 bytes of scratch otherwise): it loads them when the SNP starts
-  constexpr bool kColAhead = KT != 16;
+  constexpr bool kColAhead = KT != 16 && KT != TSAMD_NOCOL_K;
   uint32_t codes = kColAhead ? load_codes(sched[0] & 0x7fffffffu) : 0u;
   uint32_t nword[kColAhead ? kItems : 1];
+  // (default form: lam_old / eb_used live in lanes < 2K of EVERY wave and are advanced by the wave's own epilogue: lambda
+  // before the pending pass' epilogue, exp(Elogbeta) of the pass that runs; eb_ran = what the last executed pass used)
+  double eb_ran = 0.0;
   auto begin_pass = [&]() {
     fresh();
     iters += 1u;
-    lam_old = s_lam[tid < J ? tid : 0u];
-    eb_used = s_eb[tid < J ? tid : 0u];
+    const double *bsrc = kRepl ? s_ebw[tid >> 6] : s_eb;
+    if constexpr (kRepl) {
+      eb_ran = eb_used;  // (the epilogue advances eb_used; the next SNP's gamma step needs what the LAST pass used)
+    } else {
+      lam_old = s_lam[tid < J ? tid : 0u];
+      eb_used = s_eb[tid < J ? tid : 0u];
+    }
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       if constexpr (BSC) {
-        b0[k] = uniform_f64(s_eb[2 * k]);
-        b1[k] = uniform_f64(s_eb[2 * k + 1]);
+        b0[k] = uniform_f64(bsrc[2 * k]);
+        b1[k] = uniform_f64(bsrc[2 * k + 1]);
       } else if constexpr (BS) {
-        b0[k] = s_eb[2 * k];
-        b1[k] = s_eb[2 * k + 1];
+        b0[k] = bsrc[2 * k];
+        b1[k] = bsrc[2 * k + 1];
       }
       acc0[k] = acc1[k] = 0.0;
     }
@@ -788,8 +812,8 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       get_item(t, wcur);
       uint32_t zo = 0u;  // (opaque zero: the LDS reads of exp(Elogbeta) are repeated per item instead of held in 4K registers)
       if constexpr (!BS) asm volatile("" : "+v"(zo));
-      res_consume<KT, VEC, BS>(wcur, (codes >> (RC::kCodeBits * (uint32_t)t)) & RC::kMask, b0, b1, reinterpret_cast<const double2 *>(s_eb) + zo,
-                               acc0, acc1);
+      const double2 *bl = reinterpret_cast<const double2 *>(kRepl ? s_ebw[tid >> 6] : s_eb) + zo;
+      res_consume<KT, VEC, BS>(wcur, (codes >> (RC::kCodeBits * (uint32_t)t)) & RC::kMask, b0, b1, bl, acc0, acc1);
       __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef TSAMD_SCHED_TIME
@@ -803,6 +827,13 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
 #ifdef TSAMD_SCHED_TIME
     const unsigned long long tf0 = wall_clock64();
 #endif
+    // workgroup 0 publishes a deferred SNP's final lambda / exp(Elogbeta) right after a first exchange (kRepl: its second
+    // wave) and must have them out before it joins the next one: every wave waits for its own stores here, a whole sweep
+    // later (it costs nothing), ahead of the barrier that precedes the post
+    if (kRepl && pub_pending) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pub_pending = false;
+    }
     res_fold<KT>(acc0, acc1, s_red, tid);
     __syncthreads();
 #ifdef TSAMD_SCHED_TIME
@@ -829,7 +860,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     // wave) and must have them out before it joins the next exchange: whoever completes that exchange may read them.
     // A deferred SNP is published right after a first exchange; the wait stands here, a whole sweep later, where it
     // costs nothing.
-    if (pub_pending) {
+    if (!kRepl && pub_pending) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       pub_pending = false;
     }
@@ -841,6 +872,31 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     const unsigned long long te0 = wall_clock64();
     tk_xchg += te0 - tx0;
 #endif
+    if constexpr (kRepl) {
+      const uint32_t lane = tid & 63u, wave = tid >> 6;
+      if (lane < J) {
+        double nw, ebn, df;
+        epilogue_values_reg(p, lane, s_tot[lane], eb_used, lam_old, nw, ebn, df);
+        lam_old = nw;
+        eb_used = ebn;
+        s_ebw[wave][lane] = ebn;
+        s_diffw[wave][lane] = df;
+      }
+      if (deferred) {
+        if (blockIdx.x == 0) {  // the previous SNP's final epilogue and its publication: the second wave, from registers
+          if (wave == 1u && lane < J) {
+            double nw, ebn, df;
+            epilogue_values_reg(p, lane, s_tot[J + lane], s_sb[lane], s_dlam[lane], nw, ebn, df);
+            __hip_atomic_store(&p.lam[(size_t)dloc * J + lane], nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&p.eb[(size_t)dloc * J + lane], ebn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (tid == 0) count_snp_deferred(diters);
+          pub_pending = true;  // (out before this workgroup joins the next exchange: the wait at the top of finish_pass)
+        }
+        deferred = false;
+      }
+      complete = epilogue_complete(p, iters, J, s_diffw[wave]);
+    } else {
     if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);
     if (deferred && blockIdx.x == 0 && tid >= 64u && tid < 64u + J)  // the previous SNP's final epilogue, beside the new pass' one
       epilogue_values_at(p, tid - 64u, s_tot[J + tid - 64u], s_sb[tid - 64u], s_dlam[tid - 64u], s_dolam, s_doeb, s_ddiff);
@@ -857,6 +913,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       deferred = false;
     }
     complete = epilogue_complete(p, iters, J, s_diff);
+    }
 #ifdef TSAMD_SCHED_TIME
     tk_epi += wall_clock64() - te0;
 #endif
@@ -888,6 +945,12 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     fresh();
     if constexpr (!kColAhead) codes = load_codes(loc);
     __syncthreads();
+    if constexpr (kRepl) {
+      const uint32_t lane = tid & 63u, wave = tid >> 6;
+      lam_old = s_lam[lane < J ? lane : 0u];
+      eb_used = s_eb[lane < J ? lane : 0u];
+      if (lane < J) s_ebw[wave][lane] = eb_used;
+    }
     iters = 0u;
     TSAMD_TK(tk_head);
     // ---- the previous SNP's gamma step (phi from the resident weights and the exp(Elogbeta) of that
@@ -1026,10 +1089,12 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     // ---- the SNP is complete: s_lam / s_eb hold its final values (unless deferred: nobody needs them before
     // workgroup 0 has published them), eb_used the exp(Elogbeta) its last pass used.  Workgroup 0 publishes;
     // everybody keeps what the next SNP's gamma step needs.
+    // (kRepl: threads < 2K are lanes < 2K of the first wave, whose registers hold the final values)
+    const double fin_lam = kRepl ? lam_old : s_lam[tid < J ? tid : 0u], fin_eb = kRepl ? eb_used : s_eb[tid < J ? tid : 0u];
     if (!deferred && blockIdx.x == 0) {
       if (tid < J) {
-        __hip_atomic_store(&p.lam[(size_t)loc * J + tid], s_lam[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&p.eb[(size_t)loc * J + tid], s_eb[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.lam[(size_t)loc * J + tid], fin_lam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.eb[(size_t)loc * J + tid], fin_eb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (tid == 0) count_snp_deferred(iters);
       // published before this workgroup joins the next exchange (not left to the wait in finish_pass: that one would
@@ -1038,9 +1103,9 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     }
     __syncthreads();
     if (tid < J) {
-      s_sb[tid] = eb_used;
-      s_plam[tid] = s_lam[tid];  // (deferred: not the final values, and never read -- the next SNP is elsewhere)
-      s_peb[tid] = s_eb[tid];
+      s_sb[tid] = kRepl ? eb_ran : eb_used;
+      s_plam[tid] = fin_lam;  // (deferred: not the final values, and never read -- the next SNP is elsewhere)
+      s_peb[tid] = fin_eb;
     }
     pcodes = codes;
     fresh();
