@@ -433,7 +433,7 @@ def main():
     # a plain pass is 8*N_shard*K (weights) + N_shard/4 (2-bit column) algorithmic bytes;
     # the first pass (gamma step fused): R w, R gamma, W gamma, W w = 32*N*K; c_n R+W = 8N; two columns = N/2.
     # With one launch per pass the dominant kernel is the plain pass (9 of 10 launches); with the resident
-    # kernel (single GPU, K <= 8, N <= ~1M) ALL plain passes of a SNP are one launch that reads the weights
+    # kernel (single GPU, K <= 32, shards that fit the register file) ALL plain passes of a SNP are one launch that reads the weights
     # once and keeps them in registers: its algorithmic bytes per launch are passes x the plain-pass bytes.
     roofline = None
     if not args.no_profile:
