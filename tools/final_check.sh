@@ -1,7 +1,21 @@
+# the whole -m gpu suite, the driver-style bench line and the other configurations on the final build
 cd $GRAFT_REPO_ROOT
-V=$GRAFT_REPO_ROOT/terastructure_amd/lib/variants
-timeout 1500 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -2 | head -1
-for rep in 1 2 3; do for cfg in "8 4096" "8 100000" "8 1000000" "20 125000"; do set -- $cfg; for v in default old; do
-  L="TSAMD_X=1"; [ $v != default ] && L="TSAMD_LIB=$V/libtsamd_$v.so"
-  env $L python3 bench.py --pops $1 --individuals $2 --snps 50000 --steps 3000 --warmup 300 --cpu-seconds 0 --no-profile 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('K=$1 N=$2 $v:', d['value'], 'updates/s', round(1e3*d['ms_per_step'],2), 'us')"
-done; done; done
+O=gpurun_out/final; mkdir -p $O
+python3 -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/summary.txt
+timeout 3300 python3 -m pytest tests -x -q -m gpu --durations=5 > $O/t_all.log 2>&1; echo "pytest -m gpu rc=$?" | tee -a $O/summary.txt
+tail -9 $O/t_all.log
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2>$O/bench_err.log | grep '^{' > $O/bench.json; python3 -c "
+import json; d=json.load(open('$O/bench.json')); r=d['roofline']
+print('bench --steps 20 --warmup 5:', d['value'], 'updates/s;', r['bound'], r['frac'], 'hbm', r['hbm']['frac'], 'latency', r['latency']['frac_of_update'], 'cpu', d['cpu_baseline']['value'], 'parity', d['parity_vs_cpu_baseline']['ok'])" | tee -a $O/summary.txt
+bash tools/configs.sh > $O/other_configs.txt 2>&1
+python3 - <<'PY' | tee -a gpurun_out/final5/summary.txt
+import json
+for ln in open('gpurun_out/final5/other_configs.txt'):
+    if ln.startswith('###') or ln.startswith('K='): print(ln.strip())
+    if ln.startswith('{'):
+        d = json.loads(ln); r = d['roofline'] or {}
+        print('   ', d['value'], 'updates/s', 'per update us', r.get('per_update_us'), r.get('bound'), 'frac', r.get('frac'), 'cpu', (d.get('cpu_baseline') or {}).get('value'), (d.get('cpu_baseline') or {}).get('value_1_thread'), 'parity', (d.get('parity_vs_cpu_baseline') or {}).get('ok'))
+PY
+for cfg in "3 200" "8 940" "8 1718" "8 4096"; do set -- $cfg
+  python3 bench.py --pops $1 --individuals $2 --snps 50000 --steps 6000 --warmup 500 --cpu-seconds 0 --no-profile 2>/dev/null | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('K=$1 N=$2:', d['value'], 'updates/s', round(1e3*d['ms_per_step'],2), 'us')" | tee -a $O/summary.txt
+done
