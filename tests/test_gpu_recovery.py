@@ -88,3 +88,53 @@ def test_single_updates_survive_a_tenant(ts, monkeypatch):
         assert eng.recoveries() == 1
         assert_state_close(eng, orc, 1e-9, "single updates")
     orc.close()
+
+
+def test_two_engines_sharing_one_gpu(ts, monkeypatch):
+    """Two independent contexts on the same GPU, each large enough to want most of its compute units for a whole-schedule
+    launch (196 workgroups each, 256 compute units): their launches overlap in time, so at least one of them finds the
+    device taken at its entry exchange.  Neither run may fail or be poisoned: the affected context replays one launch per
+    pass; both end in the state they reach when run one after the other (the undisturbed one bit for bit, a replayed one
+    to the rounding between launch modes)."""
+    monkeypatch.setenv("TSAMD_PROBE_MS", "15")
+    n, l, k, nupd = 300_000, 16, 8, 1500
+    rng = np.random.default_rng(77)
+    data = []
+    for s in (1, 2):
+        y, _, _ = psd_genotypes(n, l, k, 90 + s, 0.02)
+        data.append((pack_bed(y), init_gamma(n, k, 95 + s), rng.integers(0, l, size=nupd).astype(np.uint32)))
+        del y
+
+    def run(concurrent):
+        engs = [ts.Engine(n, l, k) for _ in data]
+        try:
+            for e, (payload, g, _) in zip(engs, data):
+                e.upload_bed(payload)
+                e.set_gamma(g)
+            if concurrent:
+                for e, (_, _, locs) in zip(engs, data):
+                    e.run_schedule(locs)            # asynchronous: the second launch starts while the first one runs
+                for e in engs:
+                    e.synchronize()
+            else:
+                for e, (_, _, locs) in zip(engs, data):
+                    e.run_schedule(locs)
+                    e.synchronize()
+            return [(e.get_lambda(), e.get_gamma(), e.get_counts(), e.total_passes(), e.recoveries()) for e in engs]
+        finally:
+            for e in engs:
+                e.close()
+
+    alone = run(False)
+    assert [a[4] for a in alone] == [0, 0]
+    together = run(True)
+    assert sum(t[4] for t in together) >= 1, "the two launches never overlapped (nothing was tested)"
+    for a, t in zip(alone, together):
+        assert np.array_equal(a[2], t[2]) and a[3] == t[3]
+        if t[4] == 0:
+            assert np.array_equal(a[0], t[0]) and np.array_equal(a[1], t[1])
+        else:
+            from helpers import rel_err
+
+            # 1 500 updates carry the launch modes' different summation orders forward: 1e-11 in lambda, 1e-8 in gamma
+            assert rel_err(t[0], a[0]) < 1e-9 and rel_err(t[1], a[1]) < 1e-6
