@@ -158,80 +158,85 @@ __device__ __forceinline__ double digamma(double x) {
   return big ? tail : tail - num / den;
 }
 
-// 1/x for positive normal x: hardware estimate + two Newton steps (about 1 ulp), without the
-// scaling / fix-up sequence of an IEEE division.  Used where the gamma step is arithmetic-bound.
+// 1/x for positive normal x: hardware estimate r0 (relative error e, |e| < 2^-24.4 measured: tools/ubench/rcp_accuracy.hip)
+// times 1 + e + e^2 -- one third-order step, three FMAs: the error left is e^3 < 2^-73 plus the final rounding.  Without
+// the scaling / fix-up sequence of an IEEE division.  Every vector instruction costs a resident kernel's lone wave the
+// same 4.3 ... 4.7 cycles (tools/ubench/op_cost.hip), so the gamma step and the sweeps are priced in instructions.
 __device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  return fma(r, e, r);
+  const double r = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, r, 1.0);
+  return fma(r, fma(e, e, e), r);
 }
 
-// 1/sqrt(x) for positive normal x: hardware estimate + two Newton steps (about 1 ulp) instead of an IEEE
-// square root followed by an IEEE division (ts_schedule, whose gamma step is bound by its fp64 arithmetic).
+// 1/sqrt(x) for positive normal x: hardware estimate y0 (|e| = |1 - x y0^2| < 2^-23.2) times 1 + e/2 + 3 e^2/8, again one
+// third-order step (ts_schedule, whose gamma step is bound by its arithmetic).
 __device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  double e = fma(-(x * y), y, 1.0);
-  y = fma(0.5 * y, e, y);
-  e = fma(-(x * y), y, 1.0);
-  return fma(0.5 * y, e, y);
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y), y, 1.0);
+  return fma(y, e * fma(0.375, e, 0.5), y);
 }
 
 // exp(psi(x)) split as z * exp(a): z = x + 10, a = u(z) - r(x) with
 // u = -1/(2z) - sum B2n/(2n z^2n) (the asymptotic series of psi(z) - log z, |u| <= 0.051) and
 // r = sum_{i<10} 1/(x+i).  Pairing the terms i and 9-i gives r = (2x+9) * Q'(q)/Q(q) with
-// q = x(x+9) and Q(q) = prod_{i<5} (q + i(9-i)) = prod_{i<10} (x+i): a degree-5 recurrence
-// instead of a degree-10 one, and one reciprocal serves both r and 1/z.
+// q = x(x+9) and Q(q) = prod_{i<5} (q + i(9-i)) = prod_{i<10} (x+i)
+//      = q (q^4 + 60 q^3 + 1308 q^2 + 12176 q + 40320),   Q'(q) = 5 q^4 + 240 q^3 + 3924 q^2 + 24352 q + 40320:
+// two Horner chains in q with exact integer coefficients, all terms positive (nothing cancels), and one reciprocal
+// serves both r and 1/z.
 // Lets the gamma step form w[k] = z_k * exp(a_k - a_max) -- exp(Elogtheta) up to a
 // per-individual factor -- with one exp and no log per population.
 __device__ __forceinline__ void exp_digamma_split(double x, double &z, double &a) {
   const double q = x * (x + 9.0);
-  double num = 1.0, den = q;  // i = 0: q + 0
-#pragma unroll
-  for (int i = 1; i < 5; ++i) {
-    const double qi = q + (double)(i * (9 - i));
-    num = fma(num, qi, den);
-    den *= qi;
-  }
+  double den = q + 60.0;
+  den = fma(den, q, 1308.0);
+  den = fma(den, q, 12176.0);
+  den = fma(den, q, 40320.0);
+  den *= q;
+  double num = fma(5.0, q, 240.0);
+  num = fma(num, q, 3924.0);
+  num = fma(num, q, 24352.0);
+  num = fma(num, q, 40320.0);
   z = x + 10.0;
   const double inv = fast_rcp(den * z);
   const double r = (fma(2.0, x, 9.0) * num) * (z * inv);
   const double rz = den * inv;
   const double f = rz * rz;
-  double t = -1.0 / 12.0;
-  t = fma(f, t, 691.0 / 32760.0);
-  t = fma(f, t, -1.0 / 132.0);
-  t = fma(f, t, 1.0 / 240.0);
-  t = fma(f, t, -1.0 / 252.0);
-  t = fma(f, t, 1.0 / 120.0);
-  t = fma(f, t, -1.0 / 12.0);
-  a = fma(f, t, -0.5 * rz) - r;
+  // u + 1/(2z) = f P(f), f = 1/z^2 <= 0.01: degree-4 minimax fit (tools/fit/psi_tail_minimax.py; absolute error 1.0e-17, below
+  // the 4e-17 the seven-term asymptotic series -1/12 + f/120 - f^2/252 + ... leaves at z = 10)
+  double t = -0x1.ca8ce68269ac5p-8;
+  t = fma(f, t, 0x1.10a92b671fc5cp-8);
+  t = fma(f, t, -0x1.040fbe5140bffp-8);
+  t = fma(f, t, 0x1.111110ed07d8fp-7);
+  t = fma(f, t, -0x1.5555555554867p-4);
+  a = fma(rz, fma(rz, t, -0.5), -r);  // -1/(2z) + f P(f) - r
 }
 
-// exp(d) for d <= 0 (the a_k - a_max above; also fine for moderate d > 0 -- nothing here
-// depends on the sign, only overflow is not handled): two-constant Cody-Waite reduction by ln 2, degree-13
-// Taylor polynomial on |r| <= ln(2)/2 (truncation 6e-18), v_ldexp for the scaling -- which also
-// flushes the far tail to 0 -- and none of the overflow / NaN selects of the library exp.
+// exp(d) for d <= 0 (the a_k - a_max above; also fine for moderate d > 0 -- nothing here depends on the sign, only
+// overflow is not handled): n = round(d / ln 2) taken from the low bits of d / ln 2 + 1.5 * 2^52 (no rounding and no
+// conversion instruction; |d| < 1.4e9, i.e. gamma > 1e-9), two-constant Cody-Waite reduction by ln 2, degree-11 minimax
+// polynomial on |r| <= ln(2)/2, v_ldexp for the scaling -- which also flushes the far tail to 0 --
+// and none of the overflow / NaN selects of the library exp.
 __device__ __forceinline__ double exp_nonpos(double d) {
-  const double n = __builtin_rint(d * 1.4426950408889634074);
+  constexpr double kShift = 6755399441055744.0;  // 1.5 * 2^52: the sum's low word is n in two's complement
+  const double t = fma(d, 1.4426950408889634074, kShift);
+  const double n = t - kShift;
   double r = fma(n, -6.93147180369123816490e-01, d);
   r = fma(n, -1.90821492927058770002e-10, r);
-  double p = 1.0 / 6227020800.0;
-  p = fma(p, r, 1.0 / 479001600.0);
-  p = fma(p, r, 1.0 / 39916800.0);
-  p = fma(p, r, 1.0 / 3628800.0);
-  p = fma(p, r, 1.0 / 362880.0);
-  p = fma(p, r, 1.0 / 40320.0);
-  p = fma(p, r, 1.0 / 5040.0);
-  p = fma(p, r, 1.0 / 720.0);
-  p = fma(p, r, 1.0 / 120.0);
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
+  // degree-11 minimax fit of exp on |r| <= 0.3475 (tools/fit/exp_minimax.py: relative error 1.6e-17 with the coefficients
+  // rounded to double; the degree-13 Taylor polynomial it replaces left 6e-18)
+  double p = 0x1.ad64c1d19cd83p-26;
+  p = fma(p, r, 0x1.28b42b3d7df6ep-22);
+  p = fma(p, r, 0x1.71df47fc1ca59p-19);
+  p = fma(p, r, 0x1.a01991a1cec39p-16);
+  p = fma(p, r, 0x1.a01a010e063f0p-13);
+  p = fma(p, r, 0x1.6c16c187f1c93p-10);
+  p = fma(p, r, 0x1.11111111318cbp-7);
+  p = fma(p, r, 0x1.555555554f156p-5);
+  p = fma(p, r, 0x1.555555555549dp-3);
+  p = fma(p, r, 0x1.0000000000010p-1);
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
-  return __builtin_amdgcn_ldexp(p, (int)n);  // (v_cvt_i32_f64 saturates; 2^-huge flushes to 0)
+  return __builtin_amdgcn_ldexp(p, (int)(uint32_t)__double_as_longlong(t));  // (2^-huge flushes to 0)
 }
 
 // Cross-lane moves of the wave fold, all on the vector ALU (no trip through the LDS pipe):

@@ -328,8 +328,10 @@ __device__ __forceinline__ void res_consume(const typename Lanes<VEC>::T (&wv)[K
         s1 = fma(wk, b.y, s1);
       }
     }
-    c0[v] = mom * fast_rcp(s0);
-    c1[v] = dad * fast_rcp(s1);
+    // mom / s0 and dad / s1 through ONE reciprocal, of s0 * s1 (both are sums of positive terms of moderate size)
+    const double inv = fast_rcp(s0 * s1);
+    c0[v] = (mom * s1) * inv;
+    c1[v] = (dad * s0) * inv;
   }
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
@@ -969,6 +971,13 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       // selects this kernel only then), then the new weights.  An unobserved genotype takes the same instructions
       // with a step size of exactly 0: gamma keeps its bits (its update term is finite), the weights are recomputed
       // from the unchanged gamma, c_n does not count -- no select per value.
+#if defined(TSAMD_LITERAL_STEP)  // (experiments)
+      constexpr bool kLeanStep = false;
+#elif defined(TSAMD_LEAN_STEP)
+      constexpr bool kLeanStep = true;
+#else
+      constexpr bool kLeanStep = PARTIAL || KT > 8;
+#endif
       auto gamma_one = [&](double (&gx)[KT], double (&wx)[KT], uint32_t code2, uint32_t &cn) {
         double mom, dad;
         bool ok;
@@ -983,11 +992,21 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
           s1 = fma(wx[k], sbv[2 * k + 1], s1);
         }
         const double rho = ok ? fast_rsqrt(p.nodetau0 + (double)cn) : 0.0;
-        const double c0 = mom * fast_rcp(s0), c1 = dad * fast_rcp(s1);
+        if constexpr (kLeanStep) {
+          // gamma += rho (alpha + scale (y phi_mom + (2 - y) phi_dad) - gamma) as (1 - rho) gamma + rho alpha +
+          // w_k (c0 sb0_k + c1 sb1_k) with rho * scale folded into c0 / c1 and ONE reciprocal (of s0 * s1) for both
+          // parents: four instructions per population.  rho = 0 leaves gamma's bits alone (1 * gamma + 0 + w * 0).
+          const double inv = fast_rcp(s0 * s1) * (rho * p.gamma_scale);
+          const double c0 = (mom * s1) * inv, c1 = (dad * s0) * inv, keep = 1.0 - rho, ra = rho * p.alpha;
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
-          const double e = c0 * (wx[k] * sbv[2 * k]) + c1 * (wx[k] * sbv[2 * k + 1]);
-          gx[k] += rho * (p.alpha + p.gamma_scale * e - gx[k]);
+          for (int k = 0; k < KT; ++k) gx[k] = fma(wx[k], fma(c0, sbv[2 * k], c1 * sbv[2 * k + 1]), fma(keep, gx[k], ra));
+        } else {  // (the literal form, seven instructions per population: the full-size K <= 8 instantiation spills with the other)
+          const double c0 = mom * fast_rcp(s0), c1 = dad * fast_rcp(s1);
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            const double e = c0 * (wx[k] * sbv[2 * k]) + c1 * (wx[k] * sbv[2 * k + 1]);
+            gx[k] += rho * (p.alpha + p.gamma_scale * e - gx[k]);
+          }
         }
         if constexpr (KT <= 8) gamma_to_w<KT>(gx, wx); else gamma_to_w_lean<KT>(gx, wx);
         cn = ok ? cn + 1u : cn;
