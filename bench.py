@@ -550,9 +550,11 @@ def main():
                   # (1) what binds it: fp64 vector arithmetic at one wave per SIMD.  Flops per update from the SQ counters of
                   # a profiled launch when a record for this (N, K) is committed (profiles/pass_kernel_pmc.json, built from
                   # rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64), else the hand count of the kernel's own
-                  # formulation (FMA = 2): a sweep is 8K + 20 per individual (two K-term normalisers, two reciprocals, 2K
-                  # accumulations per parent), the gamma step 124K + 30 (normalisers 4K, update 12K, exp(psi) 108K).
-                  hand = ppu * sc * (8.0 * k + 20.0) + sc * (124.0 * k + 30.0)
+                  # formulation (FMA = 2): a sweep is 8K + 12 per individual (two K-term normalisers, ONE reciprocal of their
+                  # product with its third-order step, 2K accumulations per parent), the gamma step 89K + 25 (normalisers 4K,
+                  # update 7K -- 10K in the full-size K <= 8 instantiation, which keeps the literal form --, exp(psi) 78K).
+                  literal_step = k <= 8 and sc > 15 * 65536
+                  hand = ppu * sc * (8.0 * k + 12.0) + sc * ((92.0 if literal_step else 89.0) * k + 25.0)
                   flops = rec.get("fp64_flops_per_update")
                   flops_src = "hand count of the kernel's formulation (no counter record for this N, K in profiles/pass_kernel_pmc.json)"
                   if flops:
@@ -584,7 +586,8 @@ def main():
                       "bound_note": ("fp64 vector issue: the kernel runs one wave per SIMD (a thread owns the whole register file), where "
                                      "tools/fma_probe reaches 62.5 of the 78.6 TFLOP/s; the rest of the distance is the exchange latency "
                                      "(`latency`) and instructions that are not flops (register moves between the AGPR-resident weights "
-                                     "and the ALU, reciprocal refinements, code decode).  HBM is far from binding (`hbm`)."),
+                                     "and the ALU, code decode): every vector instruction costs the lone wave 4.3-4.7 cycles, "
+                                     "tools/ubench/op_cost.hip.  HBM is far from binding (`hbm`)."),
                       "hbm": {
                           "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                           "achieved": None if traffic is None else round(traffic * upd / launch_s / 1e9, 1),
