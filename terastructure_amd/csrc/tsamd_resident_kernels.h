@@ -611,8 +611,10 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   // exchanges and epilogues).  exp(Elogbeta) and the |dlambda| terms go through a per-wave LDS row only to be broadcast to
   // the wave's other lanes.  K <= 8 only; the instantiation without the skip branches (full-size shards) keeps round 2's
   // shared form -- threads < 2K, shared arrays, a barrier: with the per-wave form it no longer fits the register file.
-#ifdef TSAMD_SHARED_EPILOGUE  // (experiments)
+#if defined(TSAMD_SHARED_EPILOGUE)  // (experiments)
   constexpr bool kRepl = false;
+#elif defined(TSAMD_REPL_ALL)
+  constexpr bool kRepl = KT <= 8;
 #else
   constexpr bool kRepl = PARTIAL && KT <= 8;  // (K > 8: measured neutral to 1.5 % slower -- wider rows, more lanes in the epilogue)
 #endif
