@@ -127,17 +127,21 @@ __device__ __forceinline__ bool res_sweep(const unsigned long long *base, uint32
 }
 
 // sum of the N row pairs a wave has swept (lo / hi halves of a double sit in neighbouring lanes): on return lane 2 j
-// (j < 16) holds the total of value j of the block over rows 0, 2, 4, ... plus rows 1, 3, 5, ...
+// (j < 16) holds the total of value j of the block over rows 0, 2, 4, ... plus rows 1, 3, 5, ...  All on the vector
+// ALU: the partner's half comes over DPP (quad_perm), the other half-wave's sum over v_permlane32_swap -- through the
+// LDS crossbar (ds_bpermute, what __shfl_xor compiles to) the N dependent round trips of a leader's sweep alone cost
+// about as much as a hop of the exchange.  An even lane holds the low half and receives the high one; what the odd
+// lanes assemble from the same two words is not a number anybody reads.
 template <int N>
 __device__ __forceinline__ double res_sum(const unsigned (&v)[N], uint32_t lane) {
+  (void)lane;
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const unsigned other = (unsigned)__shfl_xor((int)v[i], 1);
-    const unsigned lo = (lane & 1u) ? other : v[i], hi = (lane & 1u) ? v[i] : other;
-    s += __longlong_as_double(((unsigned long long)hi << 32) | lo);
+    const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+    s += __longlong_as_double(((unsigned long long)other << 32) | v[i]);
   }
-  return s + __shfl_xor(s, 32);
+  return pair_add<32>(s, s);  // own + lane ^ 32
 }
 
 __device__ __forceinline__ void res_post(unsigned long long *dst, uint32_t tag, double v, int scope_system) {
