@@ -276,6 +276,15 @@ __device__ __forceinline__ double partner(double v) {
   return __longlong_as_double(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
+// a in the lanes of the banks (groups of four lanes of a 16-lane row) not in BANKS, b in the others
+template <int BANKS>
+__device__ __forceinline__ double bank_pick(double a, double b) {
+  const unsigned long long ua = __double_as_longlong(a), ub = __double_as_longlong(b);
+  const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)ua, (int)(uint32_t)ub, 0xE4 /* quad_perm [0,1,2,3] */, 0xf, BANKS, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(ua >> 32), (int)(uint32_t)(ub >> 32), 0xE4, 0xf, BANKS, false);
+  return __longlong_as_double(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
 // Sum NV per-lane values across the 64 lanes of a wave with a halving butterfly: at
 // each step a lane keeps half of its values and trades the other half with its partner,
 // so the traffic is NV + NV/2 + ... instead of 6 * NV cross-lane moves.  NV is padded to a power
@@ -305,6 +314,17 @@ struct WaveFold {
         if constexpr (off >= 16) {
 #pragma unroll
           for (int i = 0; i < h; ++i) v[i] = pair_add<off>(v[i], v[i + h]);
+        } else if constexpr (off >= 4) {
+          // the upper partners (lanes 8..15 / 4..7, 12..15 of a row: whole banks of four) keep the upper half: both picks
+          // are identity DPP moves under a bank mask -- a v_cndmask on vcc costs a lone wave 17 cycles, a DPP move 4.7
+          // (tools/ubench/op_cost.hip)
+          constexpr int up_banks = off == 8 ? 0xC : 0xA;
+#pragma unroll
+          for (int i = 0; i < h; ++i) {
+            const double keep = bank_pick<up_banks>(v[i], v[i + h]);
+            const double send = bank_pick<up_banks>(v[i + h], v[i]);
+            v[i] = keep + partner<off>(send);
+          }
         } else {
           const bool up = (lane & (uint32_t)off) != 0u;  // upper partner keeps the upper half
 #pragma unroll

@@ -407,7 +407,9 @@ __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partia
   const uint32_t begin = blockIdx.x * chunk_a, end = min(begin + chunk_a, nitems);
   const uint32_t i0 = begin + tid;
   const uint32_t cnt = (i0 < end) ? min((end - i0 + BLOCK - 1u) / BLOCK, (uint32_t)kItems) : 0u;
-  auto item_or_last = [&](uint32_t t) { return cnt ? i0 + min(t, cnt - 1u) * BLOCK : min(i0, nitems - 1u); };
+  // (item t of the thread, or its last one, or -- a thread that owns none -- the shard's last item; without a select:
+  // a thread that owns items has i0 < nitems)
+  auto item_or_last = [&](uint32_t t) { return min(i0, nitems - 1u) + min(t, max(cnt, 1u) - 1u) * BLOCK; };
   auto load_rows = [&](uint32_t i, WT (&wv)[KT]) {
 #pragma unroll
     for (int k = 0; k < KT; ++k) wv[k] = reinterpret_cast<const WT *>(w_a + (size_t)k * np)[i];
@@ -650,7 +652,9 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   // compiler hoists every address that depends only on (thread, item, row) out of that loop -- a few
   // hundred values, spilled -- so the three values they derive from are made opaque per use.
   auto fresh = [&]() { asm volatile("" : "+v"(tid), "+v"(i0), "+v"(cnt)); };
-  auto item_or_last = [&](uint32_t t) { return cnt ? i0 + min(t, cnt - 1u) * BLOCK : min(i0, nitems - 1u); };
+  // (item t of the thread, or its last one, or -- a thread that owns none -- the shard's last item; without a select:
+  // a thread that owns items has i0 < nitems)
+  auto item_or_last = [&](uint32_t t) { return min(i0, nitems - 1u) + min(t, max(cnt, 1u) - 1u) * BLOCK; };
   // items any thread of this workgroup owns (uniform).  PARTIAL (the host picks it when a workgroup's chunk leaves
   // whole items unused: shards well below the capacity): the item bodies nobody needs are skipped; the branches
   // cost the full-size kernel 5 %, so it runs without them -- an unused item is then processed as "missing".
