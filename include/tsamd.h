@@ -144,7 +144,7 @@ int tsamd_get_elogbeta(tsamd_ctx *ctx, uint32_t first_loc, uint32_t n_locs, doub
 int tsamd_snp_update(tsamd_ctx *ctx, uint32_t loc, int hol_mode, uint32_t *inner_iters);
 /* the same n times with no host round trip; asynchronous: returns after enqueueing, tsamd_synchronize() waits.
  * THE call to build on: on one GPU a whole schedule is ONE kernel launch whose weights never leave the registers
- * (12 900 updates/s at N = 1M, K = 8 against 7 750 for one tsamd_snp_update per update).  Results equal n x
+ * (13 600 updates/s at N = 1M, K = 8 against 7 750 for one tsamd_snp_update per update).  Results equal n x
  * tsamd_snp_update to rounding -- bit for bit in a given launch mode, except that a context in the default mode with
  * 4M or more weights per GPU (n x k) runs SINGLE-entry calls through the launch-per-SNP kernels, which are faster for
  * that shape and add the workgroups' partial sums in another order (rel 1e-11; TSAMD_SINGLE_ROUTE=0 disables). */
