@@ -657,8 +657,8 @@ __global__ __launch_bounds__(BLOCK, (FIRST && VEC == 1) ? TSAMD_FIRST_WAVES : 1)
         s0 = fma(w[v][k], b0[k], s0);
         s1 = fma(w[v][k], b1[k], s1);
       }
-      // (the first pass is arithmetic-bound next to its gamma step: reciprocal + two Newton steps
-      // there, IEEE division in the bandwidth-bound plain pass)
+      // (the first pass is arithmetic-bound next to its gamma step: reciprocal estimate + one third-order
+      // step there, IEEE division in the bandwidth-bound plain pass)
       c0[v] = FIRST ? mom * fast_rcp(s0) : mom / s0;
       c1[v] = FIRST ? dad * fast_rcp(s1) : dad / s1;
     }
