@@ -448,7 +448,7 @@ bool resident_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, 
   // shorter exchanges save about 10 (profiles/r03_experiments.md)
   if (one_gpu && kResOneLevelGrid > 0 && (nitems + r * (uint32_t)kResidentBlock - 1u) / (r * (uint32_t)kResidentBlock) > (uint32_t)kResOneLevelGrid) {
     const uint32_t r1 = rounds((uint32_t)kResOneLevelGrid);
-    if (r1 <= (uint32_t)resident_items((int)k) && (r1 - r) * k < 20u) r = r1;  // (measured: K = 8, N = 10 000: 39.0 against 43.7 us per update; K = 20, N = 8 000 would lose)
+    if (r1 <= (uint32_t)resident_items((int)k) && (r1 - r) * k < 20u) r = r1;  // (measured with a threshold of 16: K = 8, N = 10 000: 39.0 against 43.7 us per update; K = 20, N = 8 000 would lose)
   }
   // ... and the smallest cohorts on ONE workgroup, which exchanges nothing at all (a pass is then a sweep, a fold and an
   // epilogue: about 1 us), when its extra individuals per thread cost less than the exchanges they replace

@@ -42,7 +42,7 @@ constexpr int resident_capacity(int k) { return resident_items(k) * resident_vec
 //            (blockIdx < 8) re-reads them until every tag matches, adds them in member order, publishes sums(g);
 //   level 2: every workgroup re-reads the 8 group rows and adds them in group order (sharded: world x 8 rows in its
 //            own rank's Xchg::res_sums, written by the leaders of all ranks over xGMI).
-// A single workgroup exchanges nothing.  Up to kResOneLevelGrid = 16 workgroups on one GPU (shards up to 4 096 individuals:
+// A single workgroup exchanges nothing.  Up to kResOneLevelGrid = 32 workgroups on one GPU (shards up to 8 192 individuals:
 // the sizes of real cohorts; K <= 8 only in ts_resident) there is only ONE level: every workgroup sweeps every row.  The layouts of the two forms overlap, which
 // is harmless: an exchange is self-contained (tags never repeat).
 // A row is cut into column blocks of 32 granules (16 values); wave w of a workgroup sweeps blocks w, w + 4, ...: one
@@ -54,9 +54,9 @@ constexpr int resident_capacity(int k) { return resident_items(k) * resident_vec
 // into a no-op until the host has dealt with it (tsamd_synchronize).
 constexpr int kResGroups = 8;    // (Xchg::res_sums is laid out for these two)
 constexpr int kResMembers = 32;  // workgroups per group (grid <= 256)
-#ifndef TSAMD_ONE_LEVEL  // (experiments: 0 = always two levels; measured: 16 rows 34.5 us per update against 43.8 with two
-#define TSAMD_ONE_LEVEL 16  // levels at N = 1 718 ... 4 096, K = 8; 40 ... 63 rows 46.0 against 43.8: profiles/r03_experiments.md)
-#endif
+#ifndef TSAMD_ONE_LEVEL  // (experiments: 0 = always two levels.  Measured at K = 8: up to 16 rows 34.5 us per update against
+#define TSAMD_ONE_LEVEL 32  // 43.8 with two levels; 17 ... 32 rows -- since the row sums run on the vector ALU -- 33.8 against
+#endif                      // 37.1 at N = 16 000; 64 loses at every size: profiles/r03_experiments.md)
 constexpr int kResOneLevelGrid = TSAMD_ONE_LEVEL;  // up to this many workgroups (one GPU) the exchange has ONE level: everybody reads every row
 constexpr int res_blocks(int k) { return (4 * k + 31) / 32; }  // 32-granule column blocks of a row of 2K values
 constexpr int kResMaxGran = 32 * res_blocks(kResidentMaxK);

@@ -140,7 +140,7 @@ def test_modes_a_context_does_not_qualify_for(ts):
             eng.set_launch_mode(7)
 
 
-@pytest.mark.parametrize("n", [30_000, 6_000])      # 118 workgroups: two-level exchange; 24: one level (every workgroup reads every row)
+@pytest.mark.parametrize("n", [30_000, 6_000])      # 118 workgroups: two-level exchange; 24: one level (every workgroup reads every row, 16 row pairs per lane)
 @pytest.mark.parametrize("k", [8, 12, 20])
 def test_deferred_last_exchange_patterns(ts, k, n):
     """ts_schedule parks the row of a SNP's last pass (under the pass cap) for the next SNP's first exchange unless the
