@@ -444,11 +444,23 @@ def main():
           pass_bytes = 8.0 * sc * k + sc / 4.0
           first_bytes = 32.0 * sc * k + 8.0 * sc + sc / 2.0
 
+          pmc_stale = [None]  # why the committed counter records were not used (None: they were, or there are none for this shape)
+
           def pmc_record(want):
+              """the committed counter record for this (N, K, mode) -- only when it was collected from the kernels as they are
+              now (hash of the device sources stored with the records, tools/pmc_record.py)"""
               pmc = os.path.join(ROOT, "profiles", "pass_kernel_pmc.json")
               try:
-                  for rec in json.load(open(pmc)).get("records", []):
+                  doc = json.load(open(pmc))
+                  from terastructure_amd.build import kernel_sources_sha
+                  now, then = kernel_sources_sha(), doc.get("kernel_sources_sha")
+                  for rec in doc.get("records", []):
                       if rec.get("n") == n and rec.get("k") == k and rec.get("n_gpus") == world and rec.get("mode", "pass") == want:
+                          if then != now:
+                              pmc_stale[0] = (f"profiles/pass_kernel_pmc.json was collected from other kernel sources (sha {then}, the tree "
+                                              f"has {now}): its traffic / flops / latency figures are NOT used; re-profile "
+                                              "(tools/profile_round.sh) to refresh them")
+                              return {}
                           return rec
               except Exception:  # noqa: BLE001
                   pass
@@ -556,7 +568,8 @@ def main():
                   literal_step = k <= 8 and sc > 15 * 65536
                   hand = ppu * sc * (8.0 * k + 12.0) + sc * ((92.0 if literal_step else 89.0) * k + 25.0)
                   flops = rec.get("fp64_flops_per_update")
-                  flops_src = "hand count of the kernel's formulation (no counter record for this N, K in profiles/pass_kernel_pmc.json)"
+                  flops_src = ("hand count of the kernel's formulation (" + (pmc_stale[0] or "no counter record for this N, K in "
+                               "profiles/pass_kernel_pmc.json") + ")")
                   if flops:
                       flops_src = "SQ_INSTS_VALU_*_F64 counters of a profiled launch: " + ", ".join(rec.get("flops_source_files", []))
                   else:
@@ -617,6 +630,8 @@ def main():
                   }
           else:
               roofline = per_snp
+          if roofline is not None:
+              roofline["counter_records"] = pmc_stale[0] or "profiles/pass_kernel_pmc.json matches the kernel sources of this tree (or holds no record for this shape)"
       except Exception as exc:  # noqa: BLE001 -- the measured value must still be reported (e.g. a peer timed out in a profiling leg)
         roofline = None
         print(f"[bench] roofline legs failed, reported without them: {exc}", file=sys.stderr, flush=True)

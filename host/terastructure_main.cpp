@@ -146,6 +146,10 @@ struct Run {
   std::vector<uint8_t> text_payload;   // .012 input: the columns re-packed as PLINK codes, kept for read_column
   uint64_t bytes_per_snp = 0;
   bool columns_on_device = false;       // individual-major input: a column exists only in HBM (read_column downloads it)
+  // a resident launch that could not get its workgroups resident lowers the context to one launch per pass; the mode is
+  // raised again after `raise_in` further schedules, with a back-off that doubles while the tenant keeps coming back
+  uint32_t recoveries_seen = 0, raise_in = 0, raise_backoff = 1;
+  bool lowered = false;
 
   std::string file_str(const std::string &f) const { return prefix + f; }
   uint32_t duration() const { return (uint32_t)(time(nullptr) - start_time); }
@@ -181,6 +185,15 @@ void shard_span(const Run &r, size_t i, uint32_t &begin, uint32_t &count) {
 }
 
 void run_all(Run &r, const uint32_t *locs, uint32_t n, int hol_mode) {
+  if (r.lowered && r.ctxs.size() == 1 && --r.raise_in == 0u) {
+    // a transient tenant must not cost the rest of a multi-hour run its launch mode: try the resident kernels again
+    if (tsamd_set_launch_mode(r.ctx, TSAMD_LAUNCH_PER_SCHEDULE) == 0 || tsamd_set_launch_mode(r.ctx, TSAMD_LAUNCH_PER_SNP) == 0) {
+      r.lowered = false;
+      r.lerr("launch mode raised again after a replayed schedule (next retry distance %u schedules)", r.raise_backoff);
+    } else {
+      r.raise_in = r.raise_backoff;
+    }
+  }
   if (tsamd_run_schedule_all(r.ctxs.data(), (uint32_t)r.ctxs.size(), locs, n, hol_mode) != 0) {
     for (tsamd_ctx *c : r.ctxs)
       if (*tsamd_last_error(c)) r.ctx = c;
@@ -193,12 +206,14 @@ void run_all(Run &r, const uint32_t *locs, uint32_t n, int hol_mode) {
     }
   // a resident launch that found compute units of its GPU taken was replayed one launch per pass (include/tsamd.h,
   // tsamd_set_launch_mode): the run goes on, the log says so once per event
-  static uint32_t seen = 0;
   uint32_t now = 0;
-  if (tsamd_recoveries(r.ctx, &now) == 0 && now != seen) {
-    seen = now;
+  if (tsamd_recoveries(r.ctx, &now) == 0 && now != r.recoveries_seen) {
+    r.recoveries_seen = now;
     fprintf(stderr, "%s\n", tsamd_last_error(r.ctx));
     r.lerr("%s", tsamd_last_error(r.ctx));
+    r.lowered = true;
+    r.raise_in = r.raise_backoff;
+    r.raise_backoff = std::min<uint32_t>(r.raise_backoff * 2u, 64u);
   }
 }
 

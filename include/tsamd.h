@@ -252,6 +252,15 @@ int tsamd_probe_stream(tsamd_ctx *ctx, uint32_t reps, double *read_us, double *r
  * (1 048 576 per GPU at k <= 8, 524 288 at k = 16, 327 680 at k = 20); the whole-schedule kernel also nodekappa == 0.5.
  * TSAMD_RESIDENT=0 / TSAMD_PERSISTENT=0 in the environment disable them. */
 int tsamd_launch_info(tsamd_ctx *ctx, uint32_t *kernels_per_snp, uint32_t *plain_grid, uint32_t *first_grid);
+/* Launch geometry of the context's resident kernel of `mode` (TSAMD_LAUNCH_PER_SNP: ts_resident, TSAMD_LAUNCH_PER_SCHEDULE:
+ * ts_schedule; TSAMD_EUNSUPPORTED when the context does not qualify for it): workgroups (one per compute unit), individuals
+ * per thread (each thread of a 256-thread workgroup holds that many individuals' weights in registers), and the levels of
+ * the in-launch exchange -- 0: one workgroup, nothing is exchanged; 1: up to 32 (ts_resident: 16, k <= 8) workgroups on one
+ * GPU, every workgroup reads every row; 2: groups of up to 32 workgroups and their leaders.  Small shards are launched on
+ * fewer workgroups with more individuals per thread when that saves an exchange level.  Replaces the reference's
+ * split_all_indivs bookkeeping (src/snpsamplinge.cc:298-318: nthreads chunks of floor(n / nthreads) individuals) as the
+ * place where "who owns which individuals" is decided; tests assert the intended geometry through it. */
+int tsamd_schedule_geometry(tsamd_ctx *ctx, int mode, uint32_t *workgroups, uint32_t *indivs_per_thread, uint32_t *exchange_levels);
 /* Selects how the context launches from now on: one kernel per pass, one resident kernel for the plain passes of
  * a SNP, or one kernel per schedule.  tsamd_create picks the highest mode the context qualifies for; this call
  * can lower it and raise it again (TSAMD_EUNSUPPORTED above what the context qualifies for).  A sharded context

@@ -25,6 +25,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("TSAMD_EXTRA_HIPCC_FLAGS", "").split()
 
 
+def kernel_sources_sha():
+    """sha256 (16 hex digits) of the device sources the measured kernels are compiled from.  Stored with every counter
+    record in profiles/pass_kernel_pmc.json (tools/pmc_record.py); bench.py only uses a record's traffic / flops / latency
+    figures when the hash still matches -- a kernel change without re-profiling falls back to the hand count, visibly."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("tsamd_device.h", "tsamd_kernels.h", "tsamd_resident_kernels.h"):
+        h.update(open(os.path.join(CSRC, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

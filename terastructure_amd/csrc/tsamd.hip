@@ -119,6 +119,7 @@ struct tsamd_ctx {
   bool persistent = false;  // ... and a whole schedule runs as ONE launch (ts_schedule: the weights never leave the registers)
   bool can_resident = false, can_persistent = false;  // what the context qualifies for (tsamd_set_launch_mode)
   uint32_t sched_grid = 0, sched_chunk = 0;  // launch geometry of ts_schedule (= the plain pass' on one GPU; its own when sharded)
+  uint32_t res_grid = 0, res_chunk = 0;      // ... and of ts_resident: the same shard, shrunk only as far as ITS exchange has one level
   uint32_t device_share = 1;  // contexts whose resident kernels share this device (tests: several ranks on one GPU)
   ResXchg *res = nullptr;   // their in-launch exchange buffer
   unsigned long long *h_error = nullptr;  // pinned: tag of a bounded in-kernel wait that gave up (0: none)
@@ -297,8 +298,8 @@ int enqueue_snp(tsamd_ctx *c) {
   if (c->resident) {  // every plain pass of the SNP in one launch
     if (rc == TSAMD_OK) {
       const uint32_t par = next_parity(c);
-      kLaunchers[c->cfg.k](kLaunchResident, c->sched_grid, c->sched_chunk, c->stream, c->p, par, c->prev_rows, c->launch_serial++);
-      c->prev_rows = c->sched_grid;
+      kLaunchers[c->cfg.k](kLaunchResident, c->res_grid, c->res_chunk, c->stream, c->p, par, c->prev_rows, c->launch_serial++);
+      c->prev_rows = c->res_grid;
     }
   } else {
     for (uint32_t i = 1; rc == TSAMD_OK && i < c->cfg.max_inner; ++i) rc = enqueue_pass(c, i);
@@ -434,7 +435,10 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
 // Launch geometry of the resident kernels for a shard of `npad` padded individuals on at most `cap` workgroups (all
 // resident at once): items of resident_vec(K) individuals, a whole number of 256-thread rounds per workgroup.  False
 // when the shard does not fit resident_items(K) items per thread.
-bool resident_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, uint32_t *chunk, bool one_gpu = false) {
+// one_level: up to this many workgroups the kernel that will run exchanges in ONE level (ts_schedule: kResOneLevelGrid;
+// ts_resident: 16 at K <= 8, never above -- its sweep's registers leave no room for the wider form).
+bool resident_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, uint32_t *chunk, bool one_gpu = false,
+                       uint32_t one_level = (uint32_t)kResOneLevelGrid) {
   if (cap == 0u || (int)k > kResidentMaxK) return false;
   const uint32_t nitems = npad / (uint32_t)resident_vec((int)k);
   auto rounds = [&](uint32_t workgroups) {
@@ -446,8 +450,8 @@ bool resident_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, 
   // Small shards on one GPU: up to kResOneLevelGrid workgroups exchange in ONE level (1.9 us against 3.0 per pass), which is
   // worth a few more individuals per thread -- each costs about 0.33 K us per update (gamma step + ten sweeps), the nine
   // shorter exchanges save about 10 (profiles/r03_experiments.md)
-  if (one_gpu && kResOneLevelGrid > 0 && (nitems + r * (uint32_t)kResidentBlock - 1u) / (r * (uint32_t)kResidentBlock) > (uint32_t)kResOneLevelGrid) {
-    const uint32_t r1 = rounds((uint32_t)kResOneLevelGrid);
+  if (one_gpu && one_level > 0u && (nitems + r * (uint32_t)kResidentBlock - 1u) / (r * (uint32_t)kResidentBlock) > one_level) {
+    const uint32_t r1 = rounds(one_level);
     if (r1 <= (uint32_t)resident_items((int)k) && (r1 - r) * k < 20u) r = r1;  // (measured with a threshold of 16: K = 8, N = 10 000: 39.0 against 43.7 us per update; K = 20, N = 8 000 would lose)
   }
   // ... and the smallest cohorts on ONE workgroup, which exchanges nothing at all (a pass is then a sweep, a fold and an
@@ -669,6 +673,11 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   if (cfg->k > TSAMD_MAX_K)
     return fail(nullptr, TSAMD_EUNSUPPORTED, "k = %u above compiled maximum %d", cfg->k, TSAMD_MAX_K);
   if (cfg->max_inner == 0) return fail(nullptr, TSAMD_EINVAL, "max_inner must be >= 1");
+  // (gamma never falls below min(gamma, alpha): with both >= 1e-8 -- the smallest non-zero value of the reference's %.8f
+  // gamma.txt -- the exponent of exp(psi(gamma) - max) stays inside what exp_nonpos handles, |d| < 1.4e9)
+  if (!(cfg->alpha >= 1e-8) || !std::isfinite(cfg->alpha)) return fail(nullptr, TSAMD_EINVAL, "alpha must be finite and >= 1e-8");
+  if (!(cfg->eta0 > 0.0) || !(cfg->eta1 > 0.0) || !std::isfinite(cfg->eta0) || !std::isfinite(cfg->eta1))
+    return fail(nullptr, TSAMD_EINVAL, "eta0, eta1 must be positive and finite");
   if (cfg->world == 0 || cfg->rank >= cfg->world) return fail(nullptr, TSAMD_EINVAL, "bad rank/world");
   uint32_t b = 0, cnt = 0;
   tsamd_shard_range(cfg->n, cfg->rank, cfg->world, &b, &cnt);
@@ -744,6 +753,11 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
     const bool fits = !c->wide && cus > 0 && env_u32("TSAMD_GRID", 0) == 0u &&
                       resident_geometry(cfg->k, c->npad, std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)cus), &c->sched_grid,
                                         &c->sched_chunk, cfg->world == 1u);
+    c->res_grid = c->sched_grid;
+    c->res_chunk = c->sched_chunk;
+    if (fits)  // (ts_resident<K> instantiates its exchange with one level up to 16 workgroups at K <= 8 and never above)
+      resident_geometry(cfg->k, c->npad, std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)cus), &c->res_grid, &c->res_chunk,
+                        cfg->world == 1u, cfg->k <= 8u ? 16u : 0u);
     c->resident = fits && !c->split && cfg->world == 1 && cfg->max_inner >= 2 && cfg->max_inner <= 200 &&
                   env_u32("TSAMD_RESIDENT", 1) != 0u && kResidentBlocksPerCu[cfg->k]() >= 1;
     // ... and then, with the reference's default learning-rate exponent (the kernel carries no pow()), the whole
@@ -766,9 +780,9 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   CREATE_TRY(hipMalloc((void **)&c->d_sched, c->sched_cap * sizeof(uint32_t)));
 
   // pinned words the kernels write (DevParams::host_error): [0] error tag, [1] inner passes of the last completed SNP,
-  // [2] total passes, [3 + b] pass histogram
-  CREATE_TRY(hipHostMalloc((void **)&c->h_error, (3 + TSAMD_PASS_HIST_BINS) * sizeof(unsigned long long), hipHostMallocDefault));
-  memset(c->h_error, 0, (3 + TSAMD_PASS_HIST_BINS) * sizeof(unsigned long long));
+  // [2] total passes, [3 + b] pass histogram, [kHostDirtyWord] code of a wait that gave up after its launch had modified state
+  CREATE_TRY(hipHostMalloc((void **)&c->h_error, (kHostDirtyWord + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+  memset(c->h_error, 0, (kHostDirtyWord + 1) * sizeof(unsigned long long));
   p.host_error = c->h_error;
   if (c->resident && !alloc_res(c)) CREATE_TRY(hipErrorOutOfMemory);
   CREATE_TRY(hipMemsetAsync(p.bed, 0x55, L * p.colstride, c->stream));  // all missing
@@ -1050,7 +1064,7 @@ int tsamd_set_gamma(tsamd_ctx *c, const double *gamma) {
   SETTLE(c);
   if (!gamma) return fail(c, TSAMD_EINVAL, "null gamma");
   for (size_t i = 0; i < (size_t)c->n_local * c->cfg.k; ++i)
-    if (!(gamma[i] > 0.0) || !std::isfinite(gamma[i])) return fail(c, TSAMD_EINVAL, "gamma[%zu] must be positive and finite", i);
+    if (!(gamma[i] >= 1e-8) || !std::isfinite(gamma[i])) return fail(c, TSAMD_EINVAL, "gamma[%zu] must be finite and >= 1e-8", i);
   HIP_TRY(c, hipSetDevice(c->dev));
   if (int rc = upload_kmajor(c, gamma, c->p.gam, 1.0)) return rc;
   if (c->wide)
@@ -1278,6 +1292,16 @@ static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
                     st.idx, j.n);
       }
       HIP_TRY(c, hipMemcpyAsync(c->d_sched, j.ent, (size_t)j.n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      // The replayed kernels take the schedule from Ctl, which the ts_begin of THIS schedule set -- but a later schedule longer
+      // than sched_cap may have been enqueued before the failure was noticed: enqueue_entries then freed and reallocated
+      // d_sched while that schedule's own ts_begin was a no-op (sequence_aborted).  Point Ctl at the live buffer.
+      {
+        const uint32_t *live = c->d_sched;
+        const uint32_t len = j.n;
+        HIP_TRY(c, hipMemcpyAsync(&c->p.ctl->sched, &live, sizeof live, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&c->p.ctl->sched_len, &len, sizeof len, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // (the sources are on this stack frame)
+      }
       c->prev_rows = c->grid_first;
       for (uint32_t i = 1; rc == TSAMD_OK && i < c->cfg.max_inner; ++i) rc = enqueue_pass(c, i);
       for (uint32_t sn = st.idx + 1u; rc == TSAMD_OK && sn < j.n; ++sn) rc = enqueue_snp(c);
@@ -1306,7 +1330,10 @@ static int settle(tsamd_ctx *c) {
   if (c->h_error && *(volatile unsigned long long *)c->h_error != 0ull) {  // (written by the kernel that gave up)
     const unsigned long long err = *(volatile unsigned long long *)c->h_error;
     const unsigned long long tag = err & 0xffffffffull;
-    if ((err & kFailIntact) != 0ull && c->cfg.world == 1u && c->res && !c->recovering)
+    // (a workgroup that passed the entry exchange, modified state and only then met the abort word leaves its code here:
+    // the launch did NOT give up as a whole with its state intact, whatever the first word says)
+    const bool dirty = *(volatile unsigned long long *)(c->h_error + kHostDirtyWord) != 0ull;
+    if ((err & kFailIntact) != 0ull && !dirty && c->cfg.world == 1u && c->res && !c->recovering)
       rc = recover_from_failed_entry(c, err);
     else if (c->p2p && (c->persistent || (err & kFailIntact) != 0ull))
       rc = fail(c, TSAMD_ECOMM, "ts_schedule: the in-launch exchange across %u ranks timed out (tag %llu): a peer did not arrive, or "
@@ -1800,6 +1827,20 @@ int tsamd_launch_info(tsamd_ctx *c, uint32_t *kernels_per_snp_out, uint32_t *pla
   if (kernels_per_snp_out) *kernels_per_snp_out = c->persistent ? 0u : kernels_per_snp(c);
   if (plain_grid) *plain_grid = c->grid;
   if (first_grid) *first_grid = c->grid_first;
+  return TSAMD_OK;
+}
+
+int tsamd_schedule_geometry(tsamd_ctx *c, int mode, uint32_t *workgroups, uint32_t *indivs_per_thread, uint32_t *exchange_levels) {
+  CHECK_CTX(c);
+  if (mode != TSAMD_LAUNCH_PER_SNP && mode != TSAMD_LAUNCH_PER_SCHEDULE) return fail(c, TSAMD_EINVAL, "launch mode %d has no resident kernel", mode);
+  if ((mode == TSAMD_LAUNCH_PER_SNP && !c->can_resident) || (mode == TSAMD_LAUNCH_PER_SCHEDULE && !c->can_persistent))
+    return fail(c, TSAMD_EUNSUPPORTED, "the context does not qualify for launch mode %d", mode);
+  const bool sched = mode == TSAMD_LAUNCH_PER_SCHEDULE;
+  const uint32_t grid = sched ? c->sched_grid : c->res_grid, chunk = sched ? c->sched_chunk : c->res_chunk;
+  const uint32_t one = sched ? (uint32_t)kResOneLevelGrid : (c->cfg.k <= 8u ? 16u : 0u);
+  if (workgroups) *workgroups = grid;
+  if (indivs_per_thread) *indivs_per_thread = chunk / (uint32_t)kResidentBlock * (uint32_t)resident_vec((int)c->cfg.k);
+  if (exchange_levels) *exchange_levels = (grid == 1u && c->cfg.world == 1u) ? 0u : (c->cfg.world == 1u && grid <= one) ? 1u : 2u;
   return TSAMD_OK;
 }
 

@@ -91,6 +91,12 @@ constexpr unsigned long long kResWaitTicks = 300000000ull;  // 3 s at 100 MHz
 // modified anything yet (bit 32: no -- the failure hit its entry exchange; the state the launch started from is intact),
 // the launch parity (bit 33) and the host's launch serial (bits 34 ...)
 constexpr unsigned long long kFailIntact = 1ull << 32;
+// ... and a wait that gives up AFTER its launch has modified something also leaves its code in a second pinned word
+// (DevParams::host_error + kHostDirtyWord).  The entry exchange is one bounded wait per workgroup, and workgroups can
+// disagree on its outcome (the last row arrives right at the deadline: one workgroup gives up "intact", the others pass,
+// start modifying state and only notice the abort word at their next exchange): the host replays from the state the
+// launch started from only when this word is still clear.
+constexpr int kHostDirtyWord = 3 + TSAMD_PASS_HIST_BINS;
 __device__ __forceinline__ unsigned long long fail_code(uint32_t tag, bool intact, uint32_t par, uint32_t serial) {
   return (unsigned long long)tag | (intact ? kFailIntact : 0ull) | ((unsigned long long)(par & 1u) << 33) | ((unsigned long long)serial << 34);
 }
@@ -118,7 +124,10 @@ __device__ __forceinline__ bool res_sweep(const unsigned long long *base, uint32
     if (wall_clock64() - t0 > ticks || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
       if (lane == 0) {
         __hip_atomic_store(abort_word, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (host_flag) __hip_atomic_store(host_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (host_flag) {
+          if ((code & kFailIntact) == 0ull) __hip_atomic_store(host_flag + kHostDirtyWord, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(host_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
       return false;
     }

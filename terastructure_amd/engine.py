@@ -293,6 +293,12 @@ class Engine:
         self._check(self.h.tsamd_launch_info(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
         return dict(kernels_per_snp=a.value, plain_grid=b.value, first_grid=c.value)
 
+    def schedule_geometry(self, mode=_lib.LAUNCH_PER_SCHEDULE):
+        """dict(workgroups, indivs_per_thread, exchange_levels) of the resident kernel of `mode` -- tsamd_schedule_geometry"""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._check(self.h.tsamd_schedule_geometry(self.ctx, int(mode), C.byref(a), C.byref(b), C.byref(c)))
+        return dict(workgroups=a.value, indivs_per_thread=b.value, exchange_levels=c.value)
+
     def set_launch_mode(self, mode):
         """LAUNCH_PER_PASS / LAUNCH_PER_SNP / LAUNCH_PER_SCHEDULE -- tsamd_set_launch_mode"""
         self._check(self.h.tsamd_set_launch_mode(self.ctx, int(mode)))

@@ -138,6 +138,32 @@ def test_extreme_gamma_values(ts):
         assert np.allclose(th.sum(axis=1), 1.0, atol=1e-12)
 
 
+def test_tiniest_accepted_gamma(ts):
+    """gamma = 1e-8 (the smallest non-zero value of a %.8f gamma.txt; psi = -1e8) next to components of order 1 and on its
+    own: the exponent of exp(psi(gamma) - max) is read off the low word of d / ln 2 + 1.5 * 2^52 and must not wrap; anything
+    smaller is refused at the boundary (gamma never falls below min(gamma, alpha), so the bound holds for the whole run)."""
+    n, l, k = 512, 8, 5
+    y, _, _ = psd_genotypes(n, l, k, 41)
+    rng = np.random.default_rng(42)
+    g = rng.gamma(100.0, 0.01, size=(n, k))
+    g[rng.random((n, k)) < 0.3] = 1e-8
+    g[:8, :] = 1e-8
+    g[8:16, 1:] = 1e-8
+    eng, orc = pair_from_y(ts, y, k, 0, gamma=g)
+    with eng:
+        for loc in [0, 1, 2, 3, 1, 0]:
+            assert eng.snp_update(loc) == orc.snp_update(loc)
+        assert np.all(np.isfinite(eng.get_lambda())) and np.all(np.isfinite(eng.get_gamma()))
+        assert rel_err(eng.get_lambda(), orc.lambda_()) < 1e-9
+        assert rel_err(eng.get_gamma(), orc.gamma()) < 1e-9
+        bad = g.copy()
+        bad[3, 2] = 9e-9
+        with pytest.raises(ts.TsamdError):
+            eng.set_gamma(bad)
+    with pytest.raises(ts.TsamdError):
+        ts.Engine(n, l, k, alpha=1e-9)
+
+
 def test_same_location_many_times(ts):
     n, l, k = 2000, 4, 4
     y, _, _ = psd_genotypes(n, l, k, 41)

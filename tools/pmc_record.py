@@ -125,7 +125,13 @@ if pick(f, "FETCH_SIZE", "ts_pass<20, false") is not None:
         "algorithmic_bytes_per_launch": 160_250_000, "first_pass_algorithmic_bytes_per_launch": 648_500_000,
         "source_files": ["profiles/r03_k20_n1m_pmc_fetch_size.txt", "profiles/r03_k20_n1m_pmc_write_size.txt"],
     })
+sys.path.insert(0, ROOT)
+from terastructure_amd.build import kernel_sources_sha  # noqa: E402
+
 out = {
+    # the device sources these counters were collected from (csrc/tsamd_device.h, tsamd_kernels.h, tsamd_resident_kernels.h):
+    # bench.py ignores the records -- and says so -- when the tree's sources no longer hash to this
+    "kernel_sources_sha": kernel_sources_sha(),
     "records": records,
     "correction": ("gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams -> x2 (MI355X_MICROARCH.md, HBM "
                    "section); calibrated in round 1 on ts_refresh_w, which reads exactly 8*1000448*8 B = 64.03 MB and reports "
