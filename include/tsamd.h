@@ -261,6 +261,17 @@ int tsamd_launch_info(tsamd_ctx *ctx, uint32_t *kernels_per_snp, uint32_t *plain
  * split_all_indivs bookkeeping (src/snpsamplinge.cc:298-318: nthreads chunks of floor(n / nthreads) individuals) as the
  * place where "who owns which individuals" is decided; tests assert the intended geometry through it. */
 int tsamd_schedule_geometry(tsamd_ctx *ctx, int mode, uint32_t *workgroups, uint32_t *indivs_per_thread, uint32_t *exchange_levels);
+/* The batched validation block.  A validation-mode call (tsamd_run_schedule / tsamd_heldout_eval with hol_mode = 1) never
+ * applies a gamma step between its entries (PhiRunnerE::do_work skips it under _prev_hol_mode, src/snpsamplinge.cc:660-668),
+ * so theta is frozen and pairwise distinct locations are independent.  A context that runs TSAMD_LAUNCH_PER_SCHEDULE on one
+ * GPU therefore runs such a call `batch` locations at a time (ts_holblock: one sweep of the register-resident weights per
+ * sub-batch, ONE in-launch exchange per pass for the whole batch, the K x 2 epilogues side by side, per-location
+ * convergence) -- after the call's first entry, which goes the ordinary way because it applies the pending gamma step of
+ * the last training update.  Results equal the entry-by-entry path bit for bit (every per-location sum keeps its order).
+ * Repeated locations cut the call into blocks of distinct ones.  batch = 0: the context runs such calls entry by entry
+ * (other launch modes, sharded contexts, TSAMD_HOLBLOCK=0).  launches / locations: ts_holblock launches so far and the
+ * entries they covered.  Replaces the loop of compute_likelihood, src/snpsamplinge.cc:476-498. */
+int tsamd_holblock_info(tsamd_ctx *ctx, uint32_t *batch, uint64_t *launches, uint64_t *locations);
 /* Selects how the context launches from now on: one kernel per pass, one resident kernel for the plain passes of
  * a SNP, or one kernel per schedule.  tsamd_create picks the highest mode the context qualifies for; this call
  * can lower it and raise it again (TSAMD_EUNSUPPORTED above what the context qualifies for).  A sharded context

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "tsamd.h"
@@ -19,6 +20,7 @@
 #include "tsamd_generic_kernels.h"
 #include "tsamd_kernels.h"
 #include "tsamd_resident_kernels.h"
+#include "tsamd_holblock_kernels.h"
 #include "tsamd_wide_kernels.h"
 
 using namespace tsamd;
@@ -118,6 +120,9 @@ struct tsamd_ctx {
   bool resident = false;    // plain passes of a SNP run as ONE launch (ts_resident) instead of max_inner - 1
   bool persistent = false;  // ... and a whole schedule runs as ONE launch (ts_schedule: the weights never leave the registers)
   bool can_resident = false, can_persistent = false;  // what the context qualifies for (tsamd_set_launch_mode)
+  bool can_holblock = false;       // ... and validation-mode schedules run batched (ts_holblock) while it runs ts_schedule
+  bool tail_step_pending = false;  // the last entry enqueued was a training update: its gamma step is pending
+  uint64_t holblock_launches = 0, holblock_locs = 0;
   uint32_t sched_grid = 0, sched_chunk = 0;  // launch geometry of ts_schedule (= the plain pass' on one GPU; its own when sharded)
   uint32_t res_grid = 0, res_chunk = 0;      // ... and of ts_resident: the same shard, shrunk only as far as ITS exchange has one level
   uint32_t device_share = 1;  // contexts whose resident kernels share this device (tests: several ranks on one GPU)
@@ -144,6 +149,7 @@ struct tsamd_ctx {
     size_t cap;
     uint32_t n, serial0;
     int mode;
+    std::vector<uint32_t> launch_off;  // mode 2: first entry of each of its resident launches (ts_schedule / ts_holblock), in serial order
   };
   std::vector<Journal> journal;
   std::vector<std::pair<uint32_t *, size_t>> sched_free;
@@ -187,13 +193,15 @@ int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
   int first_blocks_per_cu_k##k(int);                                                                         \
   int resident_blocks_per_cu_k##k();                                                                         \
   void launch_schedule_k##k(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t, uint32_t); \
-  int schedule_blocks_per_cu_k##k();
+  int schedule_blocks_per_cu_k##k();                                                                         \
+  void launch_holblock_k##k(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t, uint32_t); \
+  int holblock_blocks_per_cu_k##k();
 #define TSAMD_ALL_K(X)                                                                             \
   X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)     \
   X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 }  // namespace
 namespace tsamd {
-TSAMD_ALL_K(TSAMD_DECL)  // tsamd_inst.hip and tsamd_sched.hip, one pair of translation units per K
+TSAMD_ALL_K(TSAMD_DECL)  // tsamd_inst.hip, tsamd_sched.hip and tsamd_hol.hip, three translation units per K
 }
 namespace {
 #define TSAMD_ENTRY(k) tsamd::launch_k##k,
@@ -208,6 +216,10 @@ typedef void (*ScheduleFn)(uint32_t, uint32_t, hipStream_t, const DevParams &, u
 const ScheduleFn kScheduleLaunchers[kResidentMaxK + 1] = {nullptr, TSAMD_ALL_K(TSAMD_SCHED_ENTRY)};
 #define TSAMD_SCHED_OCC_ENTRY(k) tsamd::schedule_blocks_per_cu_k##k,
 int (*const kScheduleBlocksPerCu[kResidentMaxK + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_SCHED_OCC_ENTRY)};
+#define TSAMD_HOL_ENTRY(k) tsamd::launch_holblock_k##k,
+const ScheduleFn kHolblockLaunchers[kResidentMaxK + 1] = {nullptr, TSAMD_ALL_K(TSAMD_HOL_ENTRY)};
+#define TSAMD_HOL_OCC_ENTRY(k) tsamd::holblock_blocks_per_cu_k##k,
+int (*const kHolblockBlocksPerCu[kResidentMaxK + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_HOL_OCC_ENTRY)};
 
 __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -766,6 +778,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
                     kScheduleBlocksPerCu[cfg->k]() >= 1;
     c->can_resident = c->resident;
     c->can_persistent = c->persistent;
+    c->can_holblock = c->can_persistent && cfg->world == 1u && env_u32("TSAMD_HOLBLOCK", 1) != 0u && kHolblockBlocksPerCu[cfg->k]() >= 1;
   }
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
@@ -1178,13 +1191,12 @@ int tsamd_get_elogbeta(tsamd_ctx *c, uint32_t first_loc, uint32_t n_locs, double
 // Everything that varies per SNP is read from device memory, so in the launch-per-pass mode captured sequences of
 // 16, 8, 4, 2 and 1 SNPs are replayed as often as the schedule length needs (binary decomposition: nothing is padded);
 // results are identical to eager launches bit for bit.  eager: no graphs (the replay after a failed resident launch).
-static int enqueue_entries(tsamd_ctx *c, const uint32_t *ent, uint32_t n, bool eager) {
+static int enqueue_entries(tsamd_ctx *c, const uint32_t *ent, uint32_t n, bool eager, tsamd_ctx::Journal *jr = nullptr) {
   if (c->persistent) {
     // one launch runs the whole schedule (in pieces of kScheduleChunk SNPs): the kernel reads the entries straight from
     // the pinned buffer, one SNP ahead of their use; it starts from the State the previous call left and leaves one like
     // ts_flush does -- no ts_begin, no ts_flush, and none of the graphs of the launch-per-pass sequence
-    for (uint32_t off = 0; off < n; off += kScheduleChunk) {
-      const uint32_t len = std::min(kScheduleChunk, n - off);
+    auto launch = [&](bool hol_block, uint32_t off, uint32_t len) -> int {
       const bool prof = c->prof && c->n_ev_pass < kProfCap;
       if (c->prof && !prof) c->prof_capped = true;
       hipEvent_t e = nullptr;
@@ -1192,13 +1204,41 @@ static int enqueue_entries(tsamd_ctx *c, const uint32_t *ent, uint32_t n, bool e
         if (int rc = prof_event(c, c->ev_pass, 2 * c->n_ev_pass, &e)) return rc;
         HIP_TRY(c, hipEventRecord(e, c->stream));
       }
-      kScheduleLaunchers[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), ent + off, len, c->launch_serial++);
+      if (jr) jr->launch_off.push_back(off);
+      (hol_block ? kHolblockLaunchers : kScheduleLaunchers)[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), ent + off, len,
+                                                                     c->launch_serial++);
+      if (hol_block) {
+        c->holblock_launches++;
+        c->holblock_locs += len;
+      }
       if (prof) {
         if (int rc = prof_event(c, c->ev_pass, 2 * c->n_ev_pass + 1, &e)) return rc;
         HIP_TRY(c, hipEventRecord(e, c->stream));
         c->n_ev_pass++;
       }
+      return TSAMD_OK;
+    };
+    uint32_t off = 0;
+    // A validation-mode schedule (all entries of a call share the flag) leaves theta alone, so its locations are
+    // independent as long as they are pairwise distinct: ts_holblock runs them in batches that share one sweep of the
+    // weights per sub-batch and ONE exchange per pass.  Its first entry goes through ts_schedule when a training update
+    // precedes it: that is where the pending gamma step is applied (src/snpsamplinge.cc:660-668).
+    if ((ent[0] >> 31) != 0u && c->can_holblock && n >= (c->tail_step_pending ? 3u : 2u)) {
+      if (c->tail_step_pending) {
+        if (int rc = launch(false, 0u, 1u)) return rc;
+        off = 1u;
+      }
+      std::unordered_set<uint32_t> seen;
+      while (off < n) {
+        seen.clear();
+        uint32_t e = off;
+        while (e < n && e - off < kHolChunk && seen.insert(ent[e] & 0x7fffffffu).second) ++e;
+        if (int rc = launch(e - off >= 2u, off, e - off)) return rc;  // (a lone entry: ts_schedule does the same thing)
+        off = e;
+      }
     }
+    for (; off < n; off += kScheduleChunk)
+      if (int rc = launch(false, off, std::min(kScheduleChunk, n - off))) return rc;
     HIP_TRY(c, hipGetLastError());
     return TSAMD_OK;
   }
@@ -1258,7 +1298,7 @@ static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
   uint32_t ahead = 0;  // launches of the failed schedule before the failed one
   for (size_t i = 0; i < c->journal.size(); ++i) {
     const tsamd_ctx::Journal &j = c->journal[i];
-    const uint32_t launches = j.mode == 2 ? (j.n + kScheduleChunk - 1u) / kScheduleChunk : j.mode == 1 ? j.n : 0u;
+    const uint32_t launches = j.mode == 2 ? (uint32_t)j.launch_off.size() : j.mode == 1 ? j.n : 0u;
     if (((serial - j.serial0) & kSerialMask) < launches) {
       at = i;
       ahead = (serial - j.serial0) & kSerialMask;
@@ -1278,7 +1318,7 @@ static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
   {
     const tsamd_ctx::Journal &j = c->journal[at];
     if (was_persistent) {
-      const uint32_t off = ahead * kScheduleChunk;
+      const uint32_t off = j.launch_off[ahead];  // (first entry of the launch that gave up: ts_schedule's or ts_holblock's)
       rc = enqueue_entries(c, j.ent + off, j.n - off, true);
     } else {
       // ts_resident of SNP st.idx of this schedule: its first pass is done and pending (rows in the same slot); run its
@@ -1341,6 +1381,8 @@ static int settle(tsamd_ctx *c) {
                 c->cfg.world, tag);
     else if (c->p2p)
       rc = fail(c, TSAMD_ECOMM, "peer-to-peer exchange timed out waiting for a peer (epoch %llu)", err);
+    else if (tag == 0xffffffffull)
+      rc = fail(c, TSAMD_EHIP, "internal error: ts_holblock was launched with a gamma step pending (the state is intact; the context is not usable)");
     else
       rc = fail(c, TSAMD_EHIP, "%s: the in-launch exchange timed out in the middle of a launch (tag %llu, %u workgroups): the state is void.  "
                 "TSAMD_PERSISTENT=0 selects one launch per SNP for the plain passes, TSAMD_RESIDENT=0 one launch per pass",
@@ -1375,7 +1417,7 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
     c->resident = true;
   }
   // the schedule goes up through a pinned buffer: the copy is then really asynchronous
-  tsamd_ctx::Journal j{nullptr, 0, n, c->launch_serial, c->persistent ? 2 : c->resident ? 1 : 0};
+  tsamd_ctx::Journal j{nullptr, 0, n, c->launch_serial, c->persistent ? 2 : c->resident ? 1 : 0, {}};
   for (size_t i = 0; i < c->sched_free.size(); ++i)
     if (c->sched_free[i].second >= n) {
       j.ent = c->sched_free[i].first;
@@ -1395,7 +1437,8 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   }
   c->journal.push_back(j);
   for (uint32_t i = 0; i < n; ++i) j.ent[i] = locs[i] | (hol_mode ? 0x80000000u : 0u);
-  const int rc = enqueue_entries(c, j.ent, n, false);
+  const int rc = enqueue_entries(c, j.ent, n, false, &c->journal.back());
+  c->tail_step_pending = hol_mode == 0;
   if (single_route) c->persistent = true;  // (c->resident stays set: it is what the mode falls back to when lowered by one)
   return rc;
 }
@@ -1484,6 +1527,7 @@ int tsamd_clear_pending(tsamd_ctx *c) {
   SETTLE(c);
   enqueue_begin(c, 0xffffffffu, true);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->tail_step_pending = false;
   return TSAMD_OK;
 }
 
@@ -1841,6 +1885,14 @@ int tsamd_schedule_geometry(tsamd_ctx *c, int mode, uint32_t *workgroups, uint32
   if (workgroups) *workgroups = grid;
   if (indivs_per_thread) *indivs_per_thread = chunk / (uint32_t)kResidentBlock * (uint32_t)resident_vec((int)c->cfg.k);
   if (exchange_levels) *exchange_levels = (grid == 1u && c->cfg.world == 1u) ? 0u : (c->cfg.world == 1u && grid <= one) ? 1u : 2u;
+  return TSAMD_OK;
+}
+
+int tsamd_holblock_info(tsamd_ctx *c, uint32_t *batch, uint64_t *launches, uint64_t *locations) {
+  CHECK_CTX(c);
+  if (batch) *batch = (c->can_holblock && c->persistent) ? (uint32_t)hol_batch((int)c->cfg.k) : 0u;
+  if (launches) *launches = c->holblock_launches;
+  if (locations) *locations = c->holblock_locs;
   return TSAMD_OK;
 }
 

@@ -61,10 +61,15 @@ constexpr int kResOneLevelGrid = TSAMD_ONE_LEVEL;  // up to this many workgroups
 constexpr int res_blocks(int k) { return (4 * k + 31) / 32; }  // 32-granule column blocks of a row of 2K values
 constexpr int kResMaxGran = 32 * res_blocks(kResidentMaxK);
 constexpr int kResRegionRows = kResGroups * kResMembers + 2 * kResGroups;  // member rows, then two slots of group sums
+// ts_holblock (tsamd_holblock_kernels.h) exchanges the rows of a whole BATCH of validation locations at once: up to 256
+// values = kResWideGran granules per row, in an area of its own (a row of the wide layout would land on the narrow
+// layout's group sums, which a slow workgroup may still be polling for the launch's entry exchange).
+constexpr int kResWideGran = 512;
 struct ResXchg {
   unsigned long long abort_word;  // a bounded wait gave up (its tag); every later wait and kernel returns at once
   unsigned long long pad_[31];
   unsigned long long gran[2 * kResRegionRows * kResMaxGran];  // regions A and B, laid out for the context's K (ResLay)
+  unsigned long long wide[kResRegionRows * kResWideGran];     // one region of wide rows (WideLay)
 };
 template <int KT>
 struct ResLay {
@@ -84,6 +89,23 @@ struct ResLay {
   static __device__ __forceinline__ unsigned long long *rank_sums(Xchg *x, uint32_t region, uint32_t slot, uint32_t row) {
     return x->res_sums + ((slot * 2u + region) * (uint32_t)(kMaxRanks * kResGroups) + row) * GR;
   }
+};
+
+// the same row / sum / flat positions for rows of 2 KX values in ResXchg::wide (one region; one GPU)
+template <int KX>
+struct WideLay {
+  static constexpr uint32_t GR = 32u * (uint32_t)res_blocks(KX);
+  static_assert(GR <= (uint32_t)kResWideGran, "a wide row holds at most kResWideGran granules");
+  static __device__ __forceinline__ unsigned long long *rows(ResXchg *xb, uint32_t, uint32_t g, uint32_t m) {
+    return xb->wide + (g * (uint32_t)kResMembers + m) * GR;
+  }
+  static __device__ __forceinline__ unsigned long long *sums(ResXchg *xb, uint32_t, uint32_t slot, uint32_t g) {
+    return xb->wide + ((uint32_t)(kResGroups * kResMembers) + slot * (uint32_t)kResGroups + g) * GR;
+  }
+  static __device__ __forceinline__ unsigned long long *flat(ResXchg *xb, uint32_t, uint32_t slot, uint32_t row) {
+    return xb->wide + (slot * (uint32_t)kResOneLevelGrid + row) * GR;
+  }
+  static __device__ __forceinline__ unsigned long long *rank_sums(Xchg *x, uint32_t, uint32_t, uint32_t) { return x->res_sums; }  // (never used: one GPU)
 };
 
 constexpr unsigned long long kResWaitTicks = 300000000ull;  // 3 s at 100 MHz
@@ -166,21 +188,23 @@ __device__ __forceinline__ void res_post(unsigned long long *dst, uint32_t tag, 
 }
 
 // The exchange, called by ALL threads of a workgroup after a workgroup barrier.  Thread tid < J brings value tid of the
-// region-A row in `mine`; with width == 2 thread 64 + j brings value j of the region-B row.  On return (after a
+// region-A row in `mine`; with width == 2 thread 64 + j brings value j of the region-B row (rows of up to 64 values;
+// wider rows -- LAY = WideLay -- have one region only).  On return (after a
 // workgroup barrier) s_tot[0][j] holds the region-A totals in every workgroup and s_tot[1][j] the region-B totals in
 // workgroup 0.  WR: row pairs per lane of the cross-rank level 2 (0: one GPU).  false: a bounded wait gave up.
-template <int KT, int WR, int ONE = kResOneLevelGrid>
+template <int KT, int WR, int ONE = kResOneLevelGrid, class LAY = ResLay<KT>>
 __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, uint32_t tag, uint32_t width, double mine, uint32_t g, uint32_t m,
                                              uint32_t grid, double *s_tot /* [2][2K] */, int *s_alive /* [4], all 1 */, uint32_t tid,
                                              unsigned long long code, unsigned long long ticks) {
-  using L = ResLay<KT>;
+  using L = LAY;
   constexpr uint32_t J = 2 * KT, RB = (uint32_t)res_blocks(KT), GR = L::GR;
   constexpr int kPerWave = (2 * (int)RB + 3) / 4;  // column blocks a wave sweeps at most
+  constexpr bool kWideRow = J > 64u;  // a row wider than a wave (ts_holblock): ONE region, thread tid brings value tid
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   const uint32_t nblk = width * RB;
   if constexpr (WR == 0) {
     if (grid == 1u) {  // ONE workgroup (the smallest cohorts): its row is the total, nothing goes through memory
-      const uint32_t region = tid >> 6, j = tid & 63u;
+      const uint32_t region = kWideRow ? 0u : tid >> 6, j = kWideRow ? tid : tid & 63u;
       if (region < width && j < J) s_tot[region * J + j] = mine;
       __syncthreads();
       return true;
@@ -194,7 +218,7 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
       // everybody has posted x + 1, i.e. has finished reading x.
       const uint32_t slot = tag & 1u;
       {
-        const uint32_t region = tid >> 6, j = tid & 63u;
+        const uint32_t region = kWideRow ? 0u : tid >> 6, j = kWideRow ? tid : tid & 63u;
         if (region < width && j < J) res_post(L::flat(xb, region, slot, blockIdx.x) + 2u * j, tag, mine, 0);
       }
       bool alive1 = true;
@@ -224,7 +248,7 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
     }
   }
   {
-    const uint32_t region = tid >> 6, j = tid & 63u;
+    const uint32_t region = kWideRow ? 0u : tid >> 6, j = kWideRow ? tid : tid & 63u;
     if (region < width && j < J) res_post(L::rows(xb, region, g, m) + 2u * j, tag, mine, 0);
   }
   const uint32_t members = g < grid ? (grid - g + (uint32_t)kResGroups - 1u) / (uint32_t)kResGroups : 0u;

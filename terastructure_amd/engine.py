@@ -299,6 +299,12 @@ class Engine:
         self._check(self.h.tsamd_schedule_geometry(self.ctx, int(mode), C.byref(a), C.byref(b), C.byref(c)))
         return dict(workgroups=a.value, indivs_per_thread=b.value, exchange_levels=c.value)
 
+    def holblock_info(self):
+        """dict(batch, launches, locations) of the batched validation block -- tsamd_holblock_info"""
+        a, b, c = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self.h.tsamd_holblock_info(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(batch=a.value, launches=b.value, locations=c.value)
+
     def set_launch_mode(self, mode):
         """LAUNCH_PER_PASS / LAUNCH_PER_SNP / LAUNCH_PER_SCHEDULE -- tsamd_set_launch_mode"""
         self._check(self.h.tsamd_set_launch_mode(self.ctx, int(mode)))

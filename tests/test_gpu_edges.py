@@ -141,7 +141,10 @@ def test_extreme_gamma_values(ts):
 def test_tiniest_accepted_gamma(ts):
     """gamma = 1e-8 (the smallest non-zero value of a %.8f gamma.txt; psi = -1e8) next to components of order 1 and on its
     own: the exponent of exp(psi(gamma) - max) is read off the low word of d / ln 2 + 1.5 * 2^52 and must not wrap; anything
-    smaller is refused at the boundary (gamma never falls below min(gamma, alpha), so the bound holds for the whole run)."""
+    smaller is refused at the boundary (gamma never falls below min(gamma, alpha), so the bound holds for the whole run).
+    Tolerance 1e-7 here, not 1e-9: it is the REFERENCE's formulation that loses digits at this extreme -- it adds Elogbeta
+    (order 1) to Elogtheta = psi(1e-8) - psi(sum) (order -1e8, one ulp = 1.5e-8) before the softmax, so an individual whose
+    every gamma is 1e-8 gets phi to ~1e-8 relative; the device's linear-domain weights are exact there (w_k = 10 exp(0))."""
     n, l, k = 512, 8, 5
     y, _, _ = psd_genotypes(n, l, k, 41)
     rng = np.random.default_rng(42)
@@ -154,8 +157,8 @@ def test_tiniest_accepted_gamma(ts):
         for loc in [0, 1, 2, 3, 1, 0]:
             assert eng.snp_update(loc) == orc.snp_update(loc)
         assert np.all(np.isfinite(eng.get_lambda())) and np.all(np.isfinite(eng.get_gamma()))
-        assert rel_err(eng.get_lambda(), orc.lambda_()) < 1e-9
-        assert rel_err(eng.get_gamma(), orc.gamma()) < 1e-9
+        assert rel_err(eng.get_lambda(), orc.lambda_()) < 1e-7
+        assert rel_err(eng.get_gamma(), orc.gamma()) < 1e-7
         bad = g.copy()
         bad[3, 2] = 9e-9
         with pytest.raises(ts.TsamdError):
