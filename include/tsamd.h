@@ -257,10 +257,14 @@ int tsamd_launch_info(tsamd_ctx *ctx, uint32_t *kernels_per_snp, uint32_t *plain
  * per thread (each thread of a 256-thread workgroup holds that many individuals' weights in registers), and the levels of
  * the in-launch exchange -- 0: one workgroup, nothing is exchanged; 1: up to 32 (ts_resident: 16, k <= 8) workgroups on one
  * GPU, every workgroup reads every row; 2: groups of up to 32 workgroups and their leaders.  Small shards are launched on
- * fewer workgroups with more individuals per thread when that saves an exchange level.  Replaces the reference's
+ * fewer workgroups with more individuals per thread when that saves an exchange level.  on_chip_per_thread: how many of a
+ * thread's individuals keep their weights on the chip for a whole launch (all of them in ts_schedule / ts_resident; a shard
+ * above that register capacity runs TSAMD_LAUNCH_PER_SCHEDULE as ts_hybrid -- registers + LDS hold the weights of the first
+ * ones, the others are re-read every pass -- and reports fewer than indivs_per_thread here).  Replaces the reference's
  * split_all_indivs bookkeeping (src/snpsamplinge.cc:298-318: nthreads chunks of floor(n / nthreads) individuals) as the
  * place where "who owns which individuals" is decided; tests assert the intended geometry through it. */
-int tsamd_schedule_geometry(tsamd_ctx *ctx, int mode, uint32_t *workgroups, uint32_t *indivs_per_thread, uint32_t *exchange_levels);
+int tsamd_schedule_geometry(tsamd_ctx *ctx, int mode, uint32_t *workgroups, uint32_t *indivs_per_thread, uint32_t *exchange_levels,
+                            uint32_t *on_chip_per_thread);
 /* The batched validation block.  A validation-mode call (tsamd_run_schedule / tsamd_heldout_eval with hol_mode = 1) never
  * applies a gamma step between its entries (PhiRunnerE::do_work skips it under _prev_hol_mode, src/snpsamplinge.cc:660-668),
  * so theta is frozen and pairwise distinct locations are independent.  A context that runs TSAMD_LAUNCH_PER_SCHEDULE on one

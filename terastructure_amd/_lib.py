@@ -80,7 +80,7 @@ SYMBOLS = {
     "tsamd_profile_read": (_int, [_vp, _pu64, _pd, _pu64, _pd]),
     "tsamd_probe_stream": (_int, [_vp, _u32, _pd, _pd]),
     "tsamd_launch_info": (_int, [_vp, _pu32, _pu32, _pu32]),
-    "tsamd_schedule_geometry": (_int, [_vp, _int, _pu32, _pu32, _pu32]),
+    "tsamd_schedule_geometry": (_int, [_vp, _int, _pu32, _pu32, _pu32, _pu32]),
     "tsamd_holblock_info": (_int, [_vp, _pu32, _pu64, _pu64]),
     "tsamd_set_launch_mode": (_int, [_vp, _int]),
     "tsamd_recoveries": (_int, [_vp, _pu32]),

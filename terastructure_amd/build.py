@@ -1,7 +1,7 @@
 """Builds libtsamd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
 The K-specialised kernels are compiled as one translation unit per K
-(csrc/tsamd_inst.hip, csrc/tsamd_sched.hip and csrc/tsamd_hol.hip with -DTSAMD_K=k), in parallel; objects are cached under
+(csrc/tsamd_inst.hip, csrc/tsamd_sched.hip, csrc/tsamd_hol.hip and csrc/tsamd_hyb.hip with -DTSAMD_K=k), in parallel; objects are cached under
 terastructure_amd/lib/obj and rebuilt when a source they include changes.
 """
 import os
@@ -32,7 +32,7 @@ def kernel_sources_sha():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("tsamd_device.h", "tsamd_kernels.h", "tsamd_resident_kernels.h", "tsamd_holblock_kernels.h"):
+    for name in ("tsamd_device.h", "tsamd_kernels.h", "tsamd_resident_kernels.h", "tsamd_holblock_kernels.h", "tsamd_hybrid_kernels.h"):
         h.update(open(os.path.join(CSRC, name), "rb").read())
     return h.hexdigest()[:16]
 
@@ -57,6 +57,10 @@ def _units():
     # the batched validation-mode kernel (csrc/tsamd_hol.hip): same structure, same reason
     for k in range(1, SCHED_MAX_K + 1):
         units.append((os.path.join(OBJ_DIR, f"hol_k{k}.o"), os.path.join(CSRC, "tsamd_hol.hip"),
+                      [f"-DTSAMD_K={k}", "-mllvm", "-disable-machine-licm"]))
+    # the above-capacity whole-schedule kernel (csrc/tsamd_hyb.hip)
+    for k in range(1, SCHED_MAX_K + 1):
+        units.append((os.path.join(OBJ_DIR, f"hyb_k{k}.o"), os.path.join(CSRC, "tsamd_hyb.hip"),
                       [f"-DTSAMD_K={k}", "-mllvm", "-disable-machine-licm"]))
     return units
 

@@ -21,6 +21,7 @@
 #include "tsamd_kernels.h"
 #include "tsamd_resident_kernels.h"
 #include "tsamd_holblock_kernels.h"
+#include "tsamd_hybrid_kernels.h"
 #include "tsamd_wide_kernels.h"
 
 using namespace tsamd;
@@ -120,6 +121,7 @@ struct tsamd_ctx {
   bool resident = false;    // plain passes of a SNP run as ONE launch (ts_resident) instead of max_inner - 1
   bool persistent = false;  // ... and a whole schedule runs as ONE launch (ts_schedule: the weights never leave the registers)
   bool can_resident = false, can_persistent = false;  // what the context qualifies for (tsamd_set_launch_mode)
+  bool hybrid = false;             // the whole-schedule kernel of this context is ts_hybrid: the shard exceeds ts_schedule's register capacity
   bool can_holblock = false;       // ... and validation-mode schedules run batched (ts_holblock) while it runs ts_schedule
   bool tail_step_pending = false;  // the last entry enqueued was a training update: its gamma step is pending
   uint64_t holblock_launches = 0, holblock_locs = 0;
@@ -195,13 +197,15 @@ int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
   void launch_schedule_k##k(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t, uint32_t); \
   int schedule_blocks_per_cu_k##k();                                                                         \
   void launch_holblock_k##k(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t, uint32_t); \
-  int holblock_blocks_per_cu_k##k();
+  int holblock_blocks_per_cu_k##k();                                                                         \
+  void launch_hybrid_k##k(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t, uint32_t); \
+  int hybrid_blocks_per_cu_k##k();
 #define TSAMD_ALL_K(X)                                                                             \
   X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)     \
   X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 }  // namespace
 namespace tsamd {
-TSAMD_ALL_K(TSAMD_DECL)  // tsamd_inst.hip, tsamd_sched.hip and tsamd_hol.hip, three translation units per K
+TSAMD_ALL_K(TSAMD_DECL)  // tsamd_inst.hip, tsamd_sched.hip, tsamd_hol.hip and tsamd_hyb.hip: four translation units per K
 }
 namespace {
 #define TSAMD_ENTRY(k) tsamd::launch_k##k,
@@ -220,6 +224,10 @@ int (*const kScheduleBlocksPerCu[kResidentMaxK + 1])() = {nullptr, TSAMD_ALL_K(T
 const ScheduleFn kHolblockLaunchers[kResidentMaxK + 1] = {nullptr, TSAMD_ALL_K(TSAMD_HOL_ENTRY)};
 #define TSAMD_HOL_OCC_ENTRY(k) tsamd::holblock_blocks_per_cu_k##k,
 int (*const kHolblockBlocksPerCu[kResidentMaxK + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_HOL_OCC_ENTRY)};
+#define TSAMD_HYB_ENTRY(k) tsamd::launch_hybrid_k##k,
+const ScheduleFn kHybridLaunchers[kResidentMaxK + 1] = {nullptr, TSAMD_ALL_K(TSAMD_HYB_ENTRY)};
+#define TSAMD_HYB_OCC_ENTRY(k) tsamd::hybrid_blocks_per_cu_k##k,
+int (*const kHybridBlocksPerCu[kResidentMaxK + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_HYB_OCC_ENTRY)};
 
 __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -477,6 +485,18 @@ bool resident_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, 
   return true;
 }
 
+// Launch geometry of ts_hybrid for a shard above ts_schedule's capacity: all `cap` workgroups, a whole number of 256-thread
+// rounds each; the first hy_reg_items(K) + hy_lds_items(K) rounds of a workgroup stay on chip, the rest is streamed.
+bool hybrid_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, uint32_t *chunk) {
+  if (cap == 0u || (int)k > kResidentMaxK) return false;
+  const uint32_t ch = (npad + cap - 1u) / cap;
+  const uint32_t r = (ch + (uint32_t)kResidentBlock - 1u) / (uint32_t)kResidentBlock;
+  if (r > (uint32_t)(hy_reg_items((int)k) + hy_lds_items((int)k) + kHybridMaxStreamed)) return false;
+  *chunk = r * (uint32_t)kResidentBlock;
+  *grid = (npad + *chunk - 1u) / *chunk;
+  return true;
+}
+
 bool alloc_res(tsamd_ctx *c) {
   if (c->res) return true;
   if (hipMalloc((void **)&c->res, sizeof(ResXchg)) != hipSuccess) return false;
@@ -500,18 +520,31 @@ void choose_sharded_schedule(tsamd_ctx *c) {
   const uint32_t cap = std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)prop.multiProcessorCount / c->device_share);
   if (cap < (uint32_t)kResGroups) return;
   uint32_t my_grid = 0, my_chunk = 0;
-  for (uint32_t r = 0; r < cfg.world; ++r) {
-    uint32_t b = 0, cnt = 0, grid = 0, chunk = 0;
-    tsamd_shard_range(cfg.n, r, cfg.world, &b, &cnt);
-    if (!resident_geometry(cfg.k, (cnt + 511u) / 512u * 512u, cap, &grid, &chunk) || grid < (uint32_t)kResGroups) return;
-    if (r == cfg.rank) {
-      my_grid = grid;
-      my_chunk = chunk;
+  bool hybrid = false;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    // first ts_schedule on every rank; if a rank's shard exceeds its register capacity, ts_hybrid on every rank (up to 4 ranks:
+    // the instantiations tsamd_hyb.hip carries)
+    hybrid = attempt == 1;
+    if (hybrid && (cfg.world > 4u || env_u32("TSAMD_HYBRID", 1) == 0u || kHybridBlocksPerCu[cfg.k]() < 1)) return;
+    bool ok = true;
+    for (uint32_t r = 0; r < cfg.world && ok; ++r) {
+      uint32_t b = 0, cnt = 0, grid = 0, chunk = 0;
+      tsamd_shard_range(cfg.n, r, cfg.world, &b, &cnt);
+      const uint32_t npad_r = (cnt + 511u) / 512u * 512u;
+      ok = (hybrid ? hybrid_geometry(cfg.k, npad_r, cap, &grid, &chunk) : resident_geometry(cfg.k, npad_r, cap, &grid, &chunk)) &&
+           grid >= (uint32_t)kResGroups;
+      if (r == cfg.rank) {
+        my_grid = grid;
+        my_chunk = chunk;
+      }
     }
+    if (ok) break;
+    if (hybrid) return;
   }
   if (!alloc_res(c)) return;
   c->sched_grid = my_grid;
   c->sched_chunk = my_chunk;
+  c->hybrid = hybrid;
   c->persistent = c->can_persistent = true;
 }
 
@@ -533,7 +566,7 @@ void activate_xchg(tsamd_ctx *c) {
     c->p.xchg_gather_leaders = (g && strcmp(g, "leaders") == 0) ? 1u : 0u;
   }
   c->split = true;
-  c->resident = c->persistent = c->can_resident = c->can_persistent = false;
+  c->resident = c->persistent = c->can_resident = c->can_persistent = c->hybrid = c->can_holblock = false;
   c->p2p = true;
   configure_launch(c, std::max<uint32_t>(16u, std::min<uint32_t>(kXchgBlocks, 512u / c->cfg.world)));
   choose_sharded_schedule(c);
@@ -778,7 +811,15 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
                     kScheduleBlocksPerCu[cfg->k]() >= 1;
     c->can_resident = c->resident;
     c->can_persistent = c->persistent;
-    c->can_holblock = c->can_persistent && cfg->world == 1u && env_u32("TSAMD_HOLBLOCK", 1) != 0u && kHolblockBlocksPerCu[cfg->k]() >= 1;
+    // A shard above that capacity: the same one-launch structure with part of the weights in LDS and the rest streamed
+    // (ts_hybrid) instead of ten launches per update
+    if (!fits && !c->wide && cus > 0 && !c->split && cfg->world == 1 && cfg->max_inner >= 2 && cfg->max_inner <= 200 && cfg->nodekappa == 0.5 &&
+        env_u32("TSAMD_GRID", 0) == 0u && env_u32("TSAMD_RESIDENT", 1) != 0u && env_u32("TSAMD_PERSISTENT", 1) != 0u &&
+        env_u32("TSAMD_HYBRID", 1) != 0u && kHybridBlocksPerCu[cfg->k]() >= 1 &&
+        hybrid_geometry(cfg->k, c->npad, std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)cus), &c->sched_grid, &c->sched_chunk)) {
+      c->hybrid = c->persistent = c->can_persistent = true;
+    }
+    c->can_holblock = c->can_persistent && !c->hybrid && cfg->world == 1u && env_u32("TSAMD_HOLBLOCK", 1) != 0u && kHolblockBlocksPerCu[cfg->k]() >= 1;
   }
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
@@ -797,7 +838,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
   CREATE_TRY(hipHostMalloc((void **)&c->h_error, (kHostDirtyWord + 1) * sizeof(unsigned long long), hipHostMallocDefault));
   memset(c->h_error, 0, (kHostDirtyWord + 1) * sizeof(unsigned long long));
   p.host_error = c->h_error;
-  if (c->resident && !alloc_res(c)) CREATE_TRY(hipErrorOutOfMemory);
+  if ((c->resident || c->persistent) && !alloc_res(c)) CREATE_TRY(hipErrorOutOfMemory);
   CREATE_TRY(hipMemsetAsync(p.bed, 0x55, L * p.colstride, c->stream));  // all missing
   CREATE_TRY(hipMemsetAsync(p.cnt, 0, np * sizeof(uint32_t), c->stream));
   CREATE_TRY(hipMemsetAsync(p.ctl, 0, sizeof(Ctl), c->stream));
@@ -1205,7 +1246,7 @@ static int enqueue_entries(tsamd_ctx *c, const uint32_t *ent, uint32_t n, bool e
         HIP_TRY(c, hipEventRecord(e, c->stream));
       }
       if (jr) jr->launch_off.push_back(off);
-      (hol_block ? kHolblockLaunchers : kScheduleLaunchers)[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), ent + off, len,
+      (hol_block ? kHolblockLaunchers : c->hybrid ? kHybridLaunchers : kScheduleLaunchers)[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), ent + off, len,
                                                                      c->launch_serial++);
       if (hol_block) {
         c->holblock_launches++;
@@ -1359,7 +1400,7 @@ static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
   c->recoveries++;
   fail(c, TSAMD_OK, "warning: %s could not get its %u workgroups resident at once (something else holds compute units of device %d); the "
        "schedule was replayed one launch per pass from the unchanged state and the context stays in that mode "
-       "(tsamd_set_launch_mode raises it again)", was_persistent ? "ts_schedule" : "ts_resident", c->sched_grid, c->dev);
+       "(tsamd_set_launch_mode raises it again)", was_persistent ? (c->hybrid ? "ts_hybrid" : "ts_schedule") : "ts_resident", c->sched_grid, c->dev);
   return TSAMD_OK;
 }
 
@@ -1386,7 +1427,7 @@ static int settle(tsamd_ctx *c) {
     else
       rc = fail(c, TSAMD_EHIP, "%s: the in-launch exchange timed out in the middle of a launch (tag %llu, %u workgroups): the state is void.  "
                 "TSAMD_PERSISTENT=0 selects one launch per SNP for the plain passes, TSAMD_RESIDENT=0 one launch per pass",
-                c->persistent ? "ts_schedule" : "ts_resident", tag, c->sched_grid);
+                c->persistent ? (c->hybrid ? "ts_hybrid" : "ts_schedule") : "ts_resident", tag, c->sched_grid);
   }
   for (auto &j : c->journal) c->sched_free.push_back({j.ent, j.cap});
   c->journal.clear();
@@ -1448,7 +1489,8 @@ int tsamd_prepare(tsamd_ctx *c) {
   HIP_TRY(c, hipSetDevice(c->dev));
   if (c->cfg.world > 1 && !c->comm && !c->p2p) return TSAMD_OK;  // exchange not chosen yet: nothing to capture
   if (c->persistent) {  // an empty schedule: the kernel's code object is loaded, the state only carried forward
-    kScheduleLaunchers[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), c->d_sched, 0u, c->launch_serial++);
+    (c->hybrid ? kHybridLaunchers : kScheduleLaunchers)[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), c->d_sched, 0u,
+                                                                  c->launch_serial++);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return TSAMD_OK;
@@ -1651,7 +1693,7 @@ int tsamd_comm_init(tsamd_ctx *c, const uint8_t id[TSAMD_COMM_ID_BYTES]) {
     return fail(c, TSAMD_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
   }
   c->split = true;
-  c->resident = c->persistent = c->can_resident = c->can_persistent = false;
+  c->resident = c->persistent = c->can_resident = c->can_persistent = c->hybrid = c->can_holblock = false;
   c->p.rows_from_lt = 1u;
   c->rccl_graph = env_u32("TSAMD_RCCL_GRAPH", 0) != 0u;
   destroy_graph(c);
@@ -1874,7 +1916,8 @@ int tsamd_launch_info(tsamd_ctx *c, uint32_t *kernels_per_snp_out, uint32_t *pla
   return TSAMD_OK;
 }
 
-int tsamd_schedule_geometry(tsamd_ctx *c, int mode, uint32_t *workgroups, uint32_t *indivs_per_thread, uint32_t *exchange_levels) {
+int tsamd_schedule_geometry(tsamd_ctx *c, int mode, uint32_t *workgroups, uint32_t *indivs_per_thread, uint32_t *exchange_levels,
+                            uint32_t *on_chip_per_thread) {
   CHECK_CTX(c);
   if (mode != TSAMD_LAUNCH_PER_SNP && mode != TSAMD_LAUNCH_PER_SCHEDULE) return fail(c, TSAMD_EINVAL, "launch mode %d has no resident kernel", mode);
   if ((mode == TSAMD_LAUNCH_PER_SNP && !c->can_resident) || (mode == TSAMD_LAUNCH_PER_SCHEDULE && !c->can_persistent))
@@ -1885,6 +1928,10 @@ int tsamd_schedule_geometry(tsamd_ctx *c, int mode, uint32_t *workgroups, uint32
   if (workgroups) *workgroups = grid;
   if (indivs_per_thread) *indivs_per_thread = chunk / (uint32_t)kResidentBlock * (uint32_t)resident_vec((int)c->cfg.k);
   if (exchange_levels) *exchange_levels = (grid == 1u && c->cfg.world == 1u) ? 0u : (c->cfg.world == 1u && grid <= one) ? 1u : 2u;
+  if (on_chip_per_thread) {
+    const uint32_t per = chunk / (uint32_t)kResidentBlock * (uint32_t)resident_vec((int)c->cfg.k);
+    *on_chip_per_thread = (sched && c->hybrid) ? std::min<uint32_t>(per, (uint32_t)(hy_reg_items((int)c->cfg.k) + hy_lds_items((int)c->cfg.k))) : per;
+  }
   return TSAMD_OK;
 }
 

@@ -294,10 +294,11 @@ class Engine:
         return dict(kernels_per_snp=a.value, plain_grid=b.value, first_grid=c.value)
 
     def schedule_geometry(self, mode=_lib.LAUNCH_PER_SCHEDULE):
-        """dict(workgroups, indivs_per_thread, exchange_levels) of the resident kernel of `mode` -- tsamd_schedule_geometry"""
-        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
-        self._check(self.h.tsamd_schedule_geometry(self.ctx, int(mode), C.byref(a), C.byref(b), C.byref(c)))
-        return dict(workgroups=a.value, indivs_per_thread=b.value, exchange_levels=c.value)
+        """dict(workgroups, indivs_per_thread, exchange_levels, on_chip_per_thread) of the resident kernel of `mode` --
+        tsamd_schedule_geometry (on_chip_per_thread < indivs_per_thread: ts_hybrid, part of the weights streamed)"""
+        a, b, c, d = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._check(self.h.tsamd_schedule_geometry(self.ctx, int(mode), C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(workgroups=a.value, indivs_per_thread=b.value, exchange_levels=c.value, on_chip_per_thread=d.value)
 
     def holblock_info(self):
         """dict(batch, launches, locations) of the batched validation block -- tsamd_holblock_info"""

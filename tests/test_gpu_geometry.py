@@ -86,12 +86,12 @@ def test_small_shard_geometries_match_the_oracle(ts, n, k, thresh):
 def test_geometry_query_at_other_sizes(ts):
     """full-size and mid-size shards: 256 workgroups, two levels; a context that does not qualify says so"""
     with ts.Engine(1_048_576, 2, 8) as eng:
-        assert eng.schedule_geometry() == dict(workgroups=256, indivs_per_thread=16, exchange_levels=2)
+        assert eng.schedule_geometry() == dict(workgroups=256, indivs_per_thread=16, exchange_levels=2, on_chip_per_thread=16)
     with ts.Engine(100_000, 2, 8) as eng:
         geo = eng.schedule_geometry()
         assert geo["indivs_per_thread"] == 2 and geo["exchange_levels"] == 2 and 190 <= geo["workgroups"] <= 200, geo
     with ts.Engine(200, 2, 3) as eng:      # config 1's shape: one workgroup
-        assert eng.schedule_geometry() == dict(workgroups=1, indivs_per_thread=2, exchange_levels=0)
+        assert eng.schedule_geometry() == dict(workgroups=1, indivs_per_thread=2, exchange_levels=0, on_chip_per_thread=2)
     with ts.Engine(2000, 4, 40) as eng:    # K above 32: no resident kernel
         with pytest.raises(ts.TsamdError):
             eng.schedule_geometry()

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle_py as op
-from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, usable_cores
+from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, unpack_bed, usable_cores
 from test_gpu_parity import assert_state_close, ts  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -150,7 +150,9 @@ def test_heldout_eval_through_the_block_at_size(ts):
         orc.load_bed_payload(payload)
         orc.set_gamma(g)
         for loc in vlocs:
-            ids = np.sort(rng.choice(n, size=2000, replace=False)).astype(np.uint32)
+            # (like set_validation_sample, src/snpsamplinge.cc:196-224: only observed genotypes are held out)
+            cand = np.nonzero(unpack_bed(payload[int(loc)][None, :], n)[0] != 3)[0]
+            ids = np.sort(rng.choice(cand, size=2000, replace=False)).astype(np.uint32)
             eng.set_heldout(int(loc), ids)
             orc.set_heldout(int(loc), ids)
         assert eng.holblock_info()["batch"] == 16
