@@ -1,0 +1,140 @@
+"""Shards above the register capacity of ts_schedule (ts_hybrid, csrc/tsamd_hybrid_kernels.h).
+
+The reference takes any -n / -k (src/main.cc:115-123).  ts_schedule holds 256 x 256 x resident_items(K) individuals' weights
+in registers (1 048 576 at K <= 8, 327 680 at K = 20); one more and, until round 4, the context fell back to ten launches per
+update.  ts_hybrid keeps the one-launch structure and splits a thread's individuals between registers, LDS (weights, for
+the whole launch) and memory (re-read every pass; their gamma step streams and writes back the weights as well).  Against
+the CPU oracle (rel 1e-9 on lambda / gamma, c_n and pass counts exact) for every item class: LDS items only, LDS + streamed
+items, an odd and an even number of streamed items (the pipeline takes two per turn), thresholds that stop SNPs early,
+validation-mode entries, any cut of the schedule into calls, mode switches in the middle of a run, and a launch that cannot
+be co-resident.  BASELINE config 5 on ONE GPU (N = 1M, K = 20) and its 2-GPU shard (500K) run here.
+"""
+import time
+
+import numpy as np
+import pytest
+
+import oracle_py as op
+from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, usable_cores
+from test_gpu_parity import assert_state_close, ts  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+LOCS = np.array([3, 3, 7, 1, 7, 7, 0, 2, 2, 5, 9, 11, 4, 4, 6, 8, 10, 3, 1, 0, 5, 5], dtype=np.uint32)
+
+# (n, k) -> (workgroups, individuals per thread, of which on chip)
+SHAPES = {(400_000, 20): (224, 7, 7),        # registers + 2 of 3 LDS items, nothing streamed
+          (500_000, 20): (245, 8, 8),        # config 5's 2-GPU shard: exactly registers + LDS
+          (600_000, 20): (235, 10, 8),       # two streamed items
+          (1_000_000, 20): (245, 16, 8),     # config 5 on one GPU: eight streamed items
+          (2_000_000, 8): (253, 31, 25),     # six streamed items
+          (1_100_000, 8): (253, 17, 17),     # one LDS item
+          (1_200_000, 12): (247, 19, 16),    # three streamed items (odd)
+          (300_000, 32): (235, 5, 4),        # one streamed item; two register items only
+          (1_100_000, 3): (253, 17, 17)}
+
+
+def pair(ts, n, l, k, seed, thresh=None):
+    y, _, _ = psd_genotypes(n, l, k, seed, 0.02)
+    payload = pack_bed(y)
+    g = init_gamma(n, k, seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    held = {}
+    for loc in (2, 7):
+        cand = np.nonzero(y[loc] != 3)[0]
+        held[loc] = np.sort(rng.choice(cand, size=n // 100, replace=False)).astype(np.uint32)
+    del y
+    orc = op.Oracle(n, l, k, nthreads=usable_cores(), **({} if thresh is None else {"meanchangethresh": thresh}))
+    orc.load_bed_payload(payload)
+    orc.set_gamma(g)
+    eng = ts.Engine(n, l, k, **({} if thresh is None else {"conv_thresh": thresh}))
+    eng.upload_bed(payload)
+    eng.set_gamma(g)
+    for loc, ids in held.items():
+        eng.set_heldout(loc, ids)
+        orc.set_heldout(loc, ids)
+    return eng, orc
+
+
+@pytest.mark.parametrize("n,k", sorted(SHAPES))
+def test_hybrid_matches_the_oracle(ts, n, k):
+    l = 12
+    eng, orc = pair(ts, n, l, k, 8000 + k)
+    with eng:
+        geo = eng.schedule_geometry()
+        assert (geo["workgroups"], geo["indivs_per_thread"], geo["on_chip_per_thread"]) == SHAPES[(n, k)], geo
+        assert eng.launch_info()["kernels_per_snp"] == 0 and eng.holblock_info()["batch"] == 0
+        eng.run_schedule(LOCS[:9])
+        eng.run_schedule(LOCS[9:11], 1)      # validation-mode updates: no gamma step follows them
+        eng.run_schedule(LOCS[11:12])
+        eng.run_schedule(LOCS[12:])
+        eng.synchronize()
+        its = [orc.snp_update(int(x), 1 if 9 <= i < 11 else 0) for i, x in enumerate(LOCS)]
+        assert eng.total_passes() == sum(its)
+        assert_state_close(eng, orc, 1e-9, f"ts_hybrid n {n} k {k}")
+        # single updates (a launch per call: the weights go out to memory and come back), then the other mode and back
+        for x in (5, 5, 1):
+            assert eng.snp_update(int(x)) == orc.snp_update(int(x))
+        eng.set_launch_mode(ts.LAUNCH_PER_PASS)
+        assert eng.launch_info()["kernels_per_snp"] == 10
+        eng.run_schedule(LOCS[:4])
+        eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+        eng.run_schedule(LOCS[4:8])
+        eng.synchronize()
+        for x in LOCS[:8]:
+            orc.snp_update(int(x))
+        assert_state_close(eng, orc, 1e-9, f"ts_hybrid n {n} k {k} after mode switches")
+    orc.close()
+
+
+@pytest.mark.parametrize("n,k,thresh", [(600_000, 20, 15.0), (1_200_000, 12, 30.0), (2_000_000, 8, 50.0)])
+def test_hybrid_with_early_stops_and_any_cut(ts, n, k, thresh):
+    """SNPs that stop after 1 ... 10 passes; the same schedule in one call and cut into calls gives the same bits"""
+    l = 12
+    eng, orc = pair(ts, n, l, k, 8100 + k, thresh)
+    outs = []
+    with eng:
+        eng.run_schedule(LOCS)
+        eng.synchronize()
+        its = [orc.snp_update(int(x)) for x in LOCS]
+        assert len(set(its)) >= 2, its
+        assert eng.total_passes() == sum(its)
+        hist = eng.pass_histogram()
+        assert all(hist[i] == its.count(i) for i in range(1, 11)), (hist[:12], its)
+        assert_state_close(eng, orc, 1e-9, f"ts_hybrid early stops n {n} k {k}")
+        outs.append((eng.get_lambda(), eng.get_gamma(), eng.get_counts()))
+    orc.close()
+    eng2, orc2 = pair(ts, n, l, k, 8100 + k, thresh)
+    orc2.close()
+    with eng2:
+        for a, b in ((0, 1), (1, 7), (7, 8), (8, 19), (19, len(LOCS))):
+            eng2.run_schedule(LOCS[a:b])
+        eng2.synchronize()
+        outs.append((eng2.get_lambda(), eng2.get_gamma(), eng2.get_counts()))
+    for x, z in zip(*outs):
+        assert np.array_equal(x, z)
+
+
+def test_hybrid_launch_that_cannot_be_resident_is_replayed(ts, monkeypatch):
+    monkeypatch.setenv("TSAMD_PROBE_MS", "20")
+    n, l, k = 600_000, 12, 20
+    eng, orc = pair(ts, n, l, k, 8200)
+    with eng:
+        eng.run_schedule(LOCS[:5])
+        eng.synchronize()
+        eng.debug_occupy(160, 400)
+        eng.run_schedule(LOCS[5:11])                 # cannot be resident: gives up at its entry exchange, the state intact
+        eng.run_schedule(LOCS[11:14], 1)
+        passes = eng.total_passes()                  # the replay, one launch per pass
+        assert eng.recoveries() == 1 and eng.launch_info()["kernels_per_snp"] == 10
+        its = [orc.snp_update(int(x), 1 if 11 <= i < 14 else 0) for i, x in enumerate(LOCS[:14])]
+        assert passes == sum(its)
+        assert_state_close(eng, orc, 1e-9, "ts_hybrid after the replay")
+        time.sleep(0.5)
+        eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+        eng.run_schedule(LOCS[14:])
+        eng.synchronize()
+        its += [orc.snp_update(int(x)) for x in LOCS[14:]]
+        assert eng.total_passes() == sum(its) and eng.recoveries() == 1
+        assert_state_close(eng, orc, 1e-9, "ts_hybrid raised again")
+    orc.close()

@@ -119,17 +119,25 @@ def test_switching_modes_in_the_middle_of_a_run(ts):
         assert_state_close(eng, orc, 1e-9, "mode switches")
 
 
-def test_modes_a_context_does_not_qualify_for(ts):
+def test_modes_a_context_does_not_qualify_for(ts, monkeypatch):
     with ts.Engine(2000, 4, 40) as eng:            # K above 32: the run-time-K fallback kernels, one launch per pass
         assert eng.launch_info()["kernels_per_snp"] == eng.cfg.max_inner
         for mode in (ts.LAUNCH_PER_SNP, ts.LAUNCH_PER_SCHEDULE):
             with pytest.raises(ts.TsamdError):
                 eng.set_launch_mode(mode)
         eng.set_launch_mode(ts.LAUNCH_PER_PASS)
-    with ts.Engine(400_000, 4, 20) as eng:         # K = 20 holds 5 individuals per thread: 327 680 per GPU
+    with ts.Engine(400_000, 4, 20) as eng:         # K = 20 holds 5 individuals per thread in registers: 327 680 per GPU ...
+        assert eng.launch_info()["kernels_per_snp"] == 0   # ... above that the whole-schedule kernel is ts_hybrid
+        geo = eng.schedule_geometry()
+        assert geo["indivs_per_thread"] == 7 and geo["on_chip_per_thread"] == 7 and geo["workgroups"] == 224, geo
+        with pytest.raises(ts.TsamdError):
+            eng.set_launch_mode(ts.LAUNCH_PER_SNP)         # (ts_resident has no such variant)
+    monkeypatch.setenv("TSAMD_HYBRID", "0")
+    with ts.Engine(400_000, 4, 20) as eng:         # without it: one launch per pass
         assert eng.launch_info()["kernels_per_snp"] == eng.cfg.max_inner
         with pytest.raises(ts.TsamdError):
             eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+    monkeypatch.delenv("TSAMD_HYBRID")
     with ts.Engine(327_680, 4, 20) as eng:
         assert eng.launch_info()["kernels_per_snp"] == 0
     with ts.Engine(2000, 4, 4, nodekappa=0.7) as eng:   # the whole-schedule kernel has the reference's default exponent built in
