@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all usable host cores (affinity and cgroup quota)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event pass-kernel timing leg")
+    ap.add_argument("--validation-locs", type=int, default=-1,
+                    help="validation locations of the validation-block leg (-1: the reference's sample size, floor(0.005 L), at most 5000; 0: skip)")
     ap.add_argument("--ramp-seconds", type=float, default=0.3,
                     help="untimed priming schedule queued right ahead of the warm-up (set-up; 0 = none)")
     return ap.parse_args()
@@ -658,6 +660,61 @@ def main():
             roofline["device_copy_GBps"] = None
             print(f"[bench] device copy probe skipped: {exc}", file=sys.stderr, flush=True)
 
+    # ---- the validation block (compute_likelihood, src/snpsamplinge.cc:461-544) at this configuration: the reference's sample
+    # (floor(0.005 L) locations x N/100 held-out individuals, src/snpsamplinge.cc:196-224) registered through tsamd_set_heldout,
+    # reports through tsamd_heldout_eval -- batched (ts_holblock) and, for comparison, entry by entry (TSAMD_HOLBLOCK=0).
+    # Not part of `value`: a report runs once per -rfreq training updates.
+    validation = None
+    nval = min(5000, l // 200) if args.validation_locs < 0 else min(args.validation_locs, l - 8)
+    if rank == 0 and world == 1 and nval >= 2 and not args.no_profile:
+        try:
+            try:
+                eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+            except ts.TsamdError:
+                pass
+            vrng = np.random.default_rng(args.seed + 77)
+            vlocs = np.sort(8 + vrng.choice(l - 8, size=nval, replace=False)).astype(np.uint32)
+            per_loc = n // 10 if n < 2000 else n // 100
+            tv0 = time.perf_counter()
+            for loc in vlocs:
+                eng.set_heldout(int(loc), np.sort(vrng.choice(n, size=per_loc, replace=False)).astype(np.uint32))
+            t_set = time.perf_counter() - tv0
+            train = vrng.integers(0, l, size=64).astype(np.uint32)
+
+            def report():
+                eng.run_schedule(train)        # (a report follows training: its first entry applies the pending gamma step)
+                eng.synchronize()
+                tq = time.perf_counter()
+                sq, cq, _, _ = eng.heldout_eval(vlocs, run_updates=True)
+                return time.perf_counter() - tq, sq, cq
+
+            report()
+            batched = sorted(report() for _ in range(3))[1]
+            info = eng.holblock_info()
+            os.environ["TSAMD_HOLBLOCK"] = "0"
+            try:
+                single = report()
+            finally:
+                del os.environ["TSAMD_HOLBLOCK"]
+            tq = time.perf_counter()
+            eng.heldout_eval(vlocs, run_updates=False)
+            t_eval = time.perf_counter() - tq
+            validation = {
+                "locations": int(nval), "heldout_per_location": int(per_loc), "heldout_entries": int(batched[2]),
+                "kernel": (f"ts_holblock<{k}>: {info['batch']} locations per sweep group and exchange" if info["batch"] else
+                           "entry by entry (the context does not run the batched validation kernel)"),
+                "seconds_per_report": round(batched[0], 4), "us_per_location": round(batched[0] / nval * 1e6, 2),
+                "entry_by_entry_seconds_per_report": round(single[0], 4),
+                "entry_by_entry_us_per_location": round(single[0] / nval * 1e6, 2),
+                "evaluation_only_seconds": round(t_eval, 4),
+                "mean_loglik": round(batched[1] / max(1, batched[2]), 6),
+                "set_heldout_seconds": round(t_set, 2),
+                "note": ("one report = hol-mode updates of all validation locations (theta frozen: batched) + the held-out "
+                         "log-likelihood of all entries; wall time of tsamd_heldout_eval, median of three"),
+            }
+        except Exception as exc:  # noqa: BLE001 -- an extra, never fatal
+            print(f"[bench] validation-block leg failed, reported without it: {exc}", file=sys.stderr, flush=True)
+
     # ---- CPU baseline: the oracle ("port") on the host cores, bounded sample; then the GPU ----
     # ---- repeats exactly those updates from the same start and the two states are compared ----
     cpu, parity = None, None
@@ -752,7 +809,7 @@ def main():
             "setup": {"clock_ramp_updates": ramp_n,
                       "note": ("untimed priming schedule queued right ahead of the warm-up, no synchronisation in between: the "
                                "device is at its steady clocks when the timed region starts (--ramp-seconds 0 disables)")},
-            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_baseline": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_baseline": parity, "validation_block": validation,
         }
         print(json.dumps(out), flush=True)
     eng.close()

@@ -293,7 +293,10 @@ int tsamd_holblock_info(tsamd_ctx *ctx, uint32_t *batch, uint64_t *launches, uin
  * TSAMD_LAUNCH_PER_PASS, replays the affected schedules from the unchanged state and returns success with a warning
  * in tsamd_last_error -- the results are those of an undisturbed run (to rounding, as between modes).  tsamd_recoveries
  * counts these events.  (The reference's counterpart: a run is never lost to its environment -- SIGTERM saves the
- * model, src/snpsamplinge.cc:454-457.)  Sharded contexts report TSAMD_ECOMM instead. */
+ * model, src/snpsamplinge.cc:454-457.)  A sharded context (one process per rank, tsamd_p2p_connect) does the same:
+ * the entry exchange spans the ranks, so it fails on every rank with every rank's state intact, and every rank -- driven by
+ * the same calls -- replays the same schedules one launch per pass; only the contexts of a tsamd_p2p_connect_local group
+ * (one thread settles them one after the other) still report TSAMD_ECOMM. */
 #define TSAMD_LAUNCH_PER_PASS 0
 #define TSAMD_LAUNCH_PER_SNP 1      /* first pass + ts_resident */
 #define TSAMD_LAUNCH_PER_SCHEDULE 2 /* ts_schedule */

@@ -152,9 +152,11 @@ struct tsamd_ctx {
     uint32_t n, serial0;
     int mode;
     std::vector<uint32_t> launch_off;  // mode 2: first entry of each of its resident launches (ts_schedule / ts_holblock), in serial order
+    hipEvent_t done;                   // peer-to-peer contexts: recorded behind the entry's last kernel (the journal is trimmed without a synchronise)
   };
   std::vector<Journal> journal;
   std::vector<std::pair<uint32_t *, size_t>> sched_free;
+  std::vector<hipEvent_t> event_free;
   uint32_t launch_serial = 0;   // resident launches so far (ts_resident / ts_schedule carry it; a failing one reports it)
   bool recovering = false;
   uint32_t recoveries = 0;      // times a resident launch gave up at its entry and the schedule was replayed launch per pass
@@ -701,7 +703,11 @@ void tsamd_destroy(tsamd_ctx *c) {
   hipFree(c->d_fold_orig);
   hipFree(c->d_hsums);
   if (c->h_stage) hipHostFree(c->h_stage);
-  for (auto &j : c->journal) hipHostFree(j.ent);
+  for (auto &j : c->journal) {
+    hipHostFree(j.ent);
+    if (j.done) hipEventDestroy(j.done);
+  }
+  for (auto e : c->event_free) hipEventDestroy(e);
   for (auto &b : c->sched_free) hipHostFree(b.first);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -819,7 +825,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
         hybrid_geometry(cfg->k, c->npad, std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)cus), &c->sched_grid, &c->sched_chunk)) {
       c->hybrid = c->persistent = c->can_persistent = true;
     }
-    c->can_holblock = c->can_persistent && !c->hybrid && cfg->world == 1u && env_u32("TSAMD_HOLBLOCK", 1) != 0u && kHolblockBlocksPerCu[cfg->k]() >= 1;
+    c->can_holblock = c->can_persistent && !c->hybrid && cfg->world == 1u && kHolblockBlocksPerCu[cfg->k]() >= 1;  // (TSAMD_HOLBLOCK=0: read per call)
   }
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
@@ -1264,7 +1270,7 @@ static int enqueue_entries(tsamd_ctx *c, const uint32_t *ent, uint32_t n, bool e
     // independent as long as they are pairwise distinct: ts_holblock runs them in batches that share one sweep of the
     // weights per sub-batch and ONE exchange per pass.  Its first entry goes through ts_schedule when a training update
     // precedes it: that is where the pending gamma step is applied (src/snpsamplinge.cc:660-668).
-    if ((ent[0] >> 31) != 0u && c->can_holblock && n >= (c->tail_step_pending ? 3u : 2u)) {
+    if ((ent[0] >> 31) != 0u && c->can_holblock && env_u32("TSAMD_HOLBLOCK", 1) != 0u && n >= (c->tail_step_pending ? 3u : 2u)) {
       if (c->tail_step_pending) {
         if (int rc = launch(false, 0u, 1u)) return rc;
         off = 1u;
@@ -1352,6 +1358,16 @@ static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
   const bool was_persistent = c->journal[at].mode == 2;
   *(volatile unsigned long long *)c->h_error = 0ull;
   HIP_TRY(c, hipMemsetAsync(c->res, 0, sizeof(ResXchg), c->stream));  // the abort word, and the granules of the failed exchange
+  if (c->p2p) {
+    // the failed exchange's granules in the ranks' res_sums keep its tag, and peers may still be storing them: the next
+    // resident launch (after tsamd_set_launch_mode raises the mode again) must not take them for its own -- skip the tags
+    uint32_t xseq = 0;
+    HIP_TRY(c, hipMemcpyAsync(&xseq, &c->p.ctl->xseq, sizeof xseq, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    xseq += 4096u;
+    HIP_TRY(c, hipMemcpyAsync(&c->p.ctl->xseq, &xseq, sizeof xseq, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   c->resident = c->persistent = false;
   destroy_graph(c);
   c->q = par;  // the failed launch was to write the slot of this parity: the slot of the other one holds the state to go on from
@@ -1414,7 +1430,11 @@ static int settle(tsamd_ctx *c) {
     // (a workgroup that passed the entry exchange, modified state and only then met the abort word leaves its code here:
     // the launch did NOT give up as a whole with its state intact, whatever the first word says)
     const bool dirty = *(volatile unsigned long long *)(c->h_error + kHostDirtyWord) != 0ull;
-    if ((err & kFailIntact) != 0ull && !dirty && c->cfg.world == 1u && c->res && !c->recovering)
+    // (a sharded context, one process per rank: the entry exchange spans the ranks, so it fails on EVERY rank -- nobody has
+    // written anything -- and every rank, driven by the same calls, finds the same launch in its journal and replays the
+    // same kernels.  Contexts of ONE process (tsamd_p2p_connect_local) are settled one after the other and would wait for
+    // a peer's replay that has not been enqueued yet: they keep reporting TSAMD_ECOMM.)
+    if ((err & kFailIntact) != 0ull && !dirty && (c->cfg.world == 1u || (c->p2p && c->persistent && !c->peer_maps.empty())) && c->res && !c->recovering)
       rc = recover_from_failed_entry(c, err);
     else if (c->p2p && (c->persistent || (err & kFailIntact) != 0ull))
       rc = fail(c, TSAMD_ECOMM, "ts_schedule: the in-launch exchange across %u ranks timed out (tag %llu): a peer did not arrive, or "
@@ -1429,7 +1449,10 @@ static int settle(tsamd_ctx *c) {
                 "TSAMD_PERSISTENT=0 selects one launch per SNP for the plain passes, TSAMD_RESIDENT=0 one launch per pass",
                 c->persistent ? (c->hybrid ? "ts_hybrid" : "ts_schedule") : "ts_resident", tag, c->sched_grid);
   }
-  for (auto &j : c->journal) c->sched_free.push_back({j.ent, j.cap});
+  for (auto &j : c->journal) {
+    c->sched_free.push_back({j.ent, j.cap});
+    if (j.done) c->event_free.push_back(j.done);
+  }
   c->journal.clear();
   return rc;
 }
@@ -1443,10 +1466,26 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   for (uint32_t i = 0; i < n; ++i)
     if (locs[i] >= c->cfg.l) return fail(c, TSAMD_EINVAL, "schedule[%u] = %u >= l", i, locs[i]);
   HIP_TRY(c, hipSetDevice(c->dev));
-  // a caller that streams schedules and never synchronises must not grow the journal (pinned memory) without bound
-  // (not on a peer-to-peer context: its kernels wait for peers the caller may not have enqueued yet)
+  // a caller that streams schedules and never synchronises must not grow the journal (pinned memory) without bound.
+  // A peer-to-peer context cannot simply wait here (its kernels wait for peers the caller may not have enqueued yet): it
+  // drops the entries whose kernels have finished -- an event per entry, queried, never waited for -- as long as no kernel
+  // has reported anything (a failed launch is replayed from its own entry onwards: earlier ones are not needed)
   if (!c->p2p && c->journal.size() >= 256)
     if (int rc = settle(c)) return rc;
+  if (c->p2p && c->journal.size() >= 256) {
+    size_t drop = 0;
+    while (drop < c->journal.size() && c->journal[drop].done && hipEventQuery(c->journal[drop].done) == hipSuccess &&
+           *(volatile unsigned long long *)c->h_error == 0ull)
+      ++drop;
+    (void)hipGetLastError();  // (hipErrorNotReady of the first unfinished entry)
+    for (size_t i = 0; i < drop; ++i) {
+      c->sched_free.push_back({c->journal[i].ent, c->journal[i].cap});
+      c->event_free.push_back(c->journal[i].done);
+    }
+    c->journal.erase(c->journal.begin(), c->journal.begin() + (long)drop);
+    if (c->journal.size() >= 4096)  // (nothing finishes: the peers are not being driven -- the bounded waits will say so)
+      if (int rc = settle(c)) return rc;
+  }
   // A single update per call (tsamd_snp_update) through ts_schedule pays for loading the shard's weights and the LDS
   // half of gamma and writing them back around ONE update; from about 4M weights per GPU on, the launch-per-SNP
   // sequence is the faster route for such a call (N = 1M, K = 8: 7 830 against 6 860 calls/s; N = 125K, K = 20: 8 200
@@ -1458,7 +1497,7 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
     c->resident = true;
   }
   // the schedule goes up through a pinned buffer: the copy is then really asynchronous
-  tsamd_ctx::Journal j{nullptr, 0, n, c->launch_serial, c->persistent ? 2 : c->resident ? 1 : 0, {}};
+  tsamd_ctx::Journal j{nullptr, 0, n, c->launch_serial, c->persistent ? 2 : c->resident ? 1 : 0, {}, nullptr};
   for (size_t i = 0; i < c->sched_free.size(); ++i)
     if (c->sched_free[i].second >= n) {
       j.ent = c->sched_free[i].first;
@@ -1478,8 +1517,19 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   }
   c->journal.push_back(j);
   for (uint32_t i = 0; i < n; ++i) j.ent[i] = locs[i] | (hol_mode ? 0x80000000u : 0u);
-  const int rc = enqueue_entries(c, j.ent, n, false, &c->journal.back());
+  int rc = enqueue_entries(c, j.ent, n, false, &c->journal.back());
   c->tail_step_pending = hol_mode == 0;
+  if (rc == TSAMD_OK && c->p2p) {
+    hipEvent_t ev = nullptr;
+    if (!c->event_free.empty()) {
+      ev = c->event_free.back();
+      c->event_free.pop_back();
+    } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      ev = nullptr;
+      (void)hipGetLastError();
+    }
+    if (ev && hipEventRecord(ev, c->stream) == hipSuccess) c->journal.back().done = ev;
+  }
   if (single_route) c->persistent = true;  // (c->resident stays set: it is what the mode falls back to when lowered by one)
   return rc;
 }
@@ -1937,7 +1987,7 @@ int tsamd_schedule_geometry(tsamd_ctx *c, int mode, uint32_t *workgroups, uint32
 
 int tsamd_holblock_info(tsamd_ctx *c, uint32_t *batch, uint64_t *launches, uint64_t *locations) {
   CHECK_CTX(c);
-  if (batch) *batch = (c->can_holblock && c->persistent) ? (uint32_t)hol_batch((int)c->cfg.k) : 0u;
+  if (batch) *batch = (c->can_holblock && c->persistent && env_u32("TSAMD_HOLBLOCK", 1) != 0u) ? (uint32_t)hol_batch((int)c->cfg.k) : 0u;
   if (launches) *launches = c->holblock_launches;
   if (locations) *locations = c->holblock_locs;
   return TSAMD_OK;

@@ -110,6 +110,21 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
   }
   unsigned long long tp_run = ctl->total_passes;
   uint32_t last_it = ctl->last_iters;
+#ifdef TSAMD_SCHED_TIME  // diagnostic build (tools/variant.sh UNIT=hol): where a batch's time goes, 10 ns ticks, workgroup 0
+  unsigned long long tk_setup = 0, tk_sweep = 0, tk_xchg = 0, tk_epi = 0, tk_mark = wall_clock64();
+  uint32_t tk_passes = 0u;
+  const unsigned long long tk_start = tk_mark;
+#define TSAMD_BK(acc)                               \
+  do {                                              \
+    const unsigned long long now_ = wall_clock64(); \
+    acc += now_ - tk_mark;                          \
+    tk_mark = now_;                                 \
+  } while (0)
+#else
+#define TSAMD_BK(acc) \
+  do {                \
+  } while (0)
+#endif
   auto count_snp_deferred = [&](uint32_t its) {  // (as in ts_schedule: fire-and-forget histogram bump, totals in registers)
     const uint32_t bin = min(its, (uint32_t)TSAMD_PASS_HIST_BINS - 1u);
     __hip_atomic_fetch_add(&ctl->pass_hist[bin], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -158,6 +173,7 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
     uint32_t active = nb >= 32u ? 0xffffffffu : (1u << nb) - 1u;  // (uniform) locations of the batch whose inner loop still runs
     uint32_t pass = 0u;
     __syncthreads();
+    TSAMD_BK(tk_setup);
     while (active != 0u) {
       pass += 1u;
       fresh();
@@ -195,6 +211,7 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
         for (int bb = 0; bb < BA; ++bb) res_fold<KT>(acc0[bb], acc1[bb], &s_red[sub * BA + bb][0][0], tid);
       }
       __syncthreads();
+      TSAMD_BK(tk_sweep);
       fresh();
       double mine = 0.0;
       if (tid < JX) {
@@ -207,6 +224,7 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
       if (!res_exchange<KX, 0, kResOneLevelGrid, Wide>(xb, p, tag, 1u, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial),
                                                        kResWaitTicks))
         return;
+      TSAMD_BK(tk_xchg);
       // the BX epilogues, one lane per (location, value); the pair sum comes from the neighbouring lane (J is even)
       if (vact) {
         double nw, ebn, df;
@@ -233,6 +251,10 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
         for (uint32_t b = 0; b < nb; ++b)
           if ((done >> b) & 1u) count_snp_deferred(pass);
       active &= ~done;
+      TSAMD_BK(tk_epi);
+#ifdef TSAMD_SCHED_TIME
+      tk_passes += 1u;
+#endif
     }
     // the schedule's last location leaves the State the next call starts from (as ts_schedule: its final lambda, the
     // exp(Elogbeta) its LAST executed pass used; validation mode: no gamma step will follow)
@@ -263,12 +285,20 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
       ctl->total_passes = tp_run;
       if (p.host_error) __hip_atomic_store(p.host_error + 2, tp_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the histogram atomics of this thread have landed)
+#ifdef TSAMD_SCHED_TIME
+      if (n_sched >= 16u)
+        printf("ts_holblock n=%u batch %d passes of batches %u | per location (us): setup %.2f sweeps+folds %.2f exchanges %.2f epilogues %.2f | "
+               "per batch pass (us): sweeps+folds %.2f exchange %.2f epilogue %.2f | whole launch %.1f us\n", n_sched, BX, tk_passes,
+               tk_setup * 0.01 / n_sched, tk_sweep * 0.01 / n_sched, tk_xchg * 0.01 / n_sched, tk_epi * 0.01 / n_sched, tk_sweep * 0.01 / tk_passes,
+               tk_xchg * 0.01 / tk_passes, tk_epi * 0.01 / tk_passes, (wall_clock64() - tk_start) * 0.01);
+#endif
     }
     __syncthreads();
     if (p.host_error && tid < (uint32_t)TSAMD_PASS_HIST_BINS)
       __hip_atomic_store(p.host_error + 3 + tid, __hip_atomic_load(&ctl->pass_hist[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+#undef TSAMD_BK
 }
 
 }  // namespace tsamd

@@ -72,8 +72,16 @@ def main():
         eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
         eng.run_schedule(locs[20:])
     else:
+        if os.environ.get("TS_OCCUPY") and rank == 0:   # "workgroups,milliseconds": a tenant takes compute units of rank 0's device
+            wgs, ms = (int(x) for x in os.environ["TS_OCCUPY"].split(","))
+            eng.debug_occupy(wgs, ms)
+        if os.environ.get("TS_OCCUPY"):
+            d.barrier()
         eng.run_schedule(locs[6:])      # graph replay path when long enough
     eng.synchronize()
+    if os.environ.get("TS_EXPECT_RECOVERIES"):
+        assert eng.recoveries() == int(os.environ["TS_EXPECT_RECOVERIES"]), f"recoveries: {eng.recoveries()} ({eng.last_error()})"
+        assert eng.launch_info()["kernels_per_snp"] == eng.cfg.max_inner
     full = tdist.gather_rows(eng.get_gamma(), n, d, ts.shard_range)
     cnt = tdist.gather_rows(eng.get_counts().astype(np.float64)[:, None], n, d, ts.shard_range)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), lam=eng.get_lambda(), gamma=full, cnt=cnt, its=np.array(its),

@@ -186,6 +186,18 @@ def test_sharded_ranks_switch_launch_modes_mid_run(tmp_path, world):
     _assert_ranks_match(res, orc, its)
 
 
+@pytest.mark.parametrize("world,n,k", [(2, 40_000, 8), (3, 30_000, 20)])
+def test_sharded_schedule_that_cannot_be_resident_is_replayed_on_every_rank(tmp_path, world, n, k):
+    """A tenant holds compute units when the ranks' ts_schedule launches start: the entry exchange (which spans the ranks)
+    times out on every rank with every rank's state intact; every rank lowers itself to one launch per pass and replays the
+    same schedule from its journal -- the results are those of an undisturbed run."""
+    l, seed, nsnp = 32, 93, 30
+    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp,
+                     extra_env={"TS_EXPECT_KPS": "0", "TS_OCCUPY": "200,4500", "TS_EXPECT_RECOVERIES": "1"})
+    orc, its = _oracle_run(n, l, k, seed, nsnp)
+    _assert_ranks_match(res, orc, its)
+
+
 def test_rccl_two_ranks_matches_oracle(tmp_path):
     """The RCCL all-reduce exchange with more than one rank.  On a box with fewer GPUs than ranks
     RCCL refuses the communicator (two ranks on one device): skipped there, with RCCL's message."""

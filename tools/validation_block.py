@@ -1,7 +1,8 @@
 """The validation block (compute_likelihood, src/snpsamplinge.cc:461-544) at BASELINE config 4 on one GPU: the reference's
 validation sample (0.5 % of the locations, N/100 held-out individuals each: 5 000 x 10 000 entries at N = L = 1M) and
 the time of one report: a hol-mode schedule over the validation locations + one evaluation kernel
-(tsamd_heldout_eval).   usage (GPU box): python tools/validation_block.py [L = 1000000]"""
+(tsamd_heldout_eval; batched through ts_holblock, TSAMD_HOLBLOCK=0 for the entry-by-entry path).
+usage (GPU box): python tools/validation_block.py [L = 1000000]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
@@ -29,5 +30,9 @@ for rep in range(3):
     t0 = time.time()
     s, c, _, _ = e.heldout_eval(vlocs, run_updates=True)
     t1 = time.time()
+    t2 = time.time()
+    e.heldout_eval(vlocs, run_updates=False)
+    t3 = time.time()
     print(f"report {rep}: {len(vlocs)} hol-mode updates + evaluation of {c} entries in {t1 - t0:.3f} s "
-          f"({(t1 - t0) / len(vlocs) * 1e6:.1f} us per validation location), mean log-likelihood {s / c:.6f}", flush=True)
+          f"({(t1 - t0) / len(vlocs) * 1e6:.1f} us per validation location; the evaluation alone: {t3 - t2:.3f} s), "
+          f"mean log-likelihood {s / c:.6f}; {e.holblock_info()}", flush=True)

@@ -2,7 +2,8 @@
 # Builds a variant of libtsamd.so whose K-specialised kernels for one K are compiled with extra
 # flags (ablations / tuning experiments):  tools/variant.sh <name> <K> <hipcc flags...>
 # -> terastructure_amd/lib/variants/libtsamd_<name>.so ; select it with TSAMD_LIB=<path>.
-# UNIT=sched builds the variant of the whole-schedule kernel's unit (csrc/tsamd_sched.hip) instead;
+# UNIT=sched builds the variant of the whole-schedule kernel's unit (csrc/tsamd_sched.hip) instead; UNIT=hol / UNIT=hyb that
+# of ts_holblock / ts_hybrid (-DTSAMD_SCHED_TIME: their in-kernel timers);
 # UNIT=all recompiles the per-K unit, the whole-schedule unit AND the host (csrc/tsamd.hip) with the flags
 # (variants that change the resident kernels' geometry: -DTSAMD_RES_VEC / -DTSAMD_RES_ITEMS).
 set -e
@@ -20,6 +21,10 @@ fi
 if [ "$U" = sched ] || [ "$U" = all ]; then
   $CC -mllvm -disable-machine-licm -DTSAMD_K=$K "$@" -o $D/v_sched_k${K}_$NAME.o terastructure_amd/csrc/tsamd_sched.hip &
   NEW="$NEW $D/v_sched_k${K}_$NAME.o"; SKIP="$SKIP|/sched_k${K}\.o"
+fi
+if [ "$U" = hol ] || [ "$U" = hyb ]; then   # the batched validation kernel / the above-capacity kernel (csrc/tsamd_hol.hip, tsamd_hyb.hip)
+  $CC -mllvm -disable-machine-licm -DTSAMD_K=$K "$@" -o $D/v_${U}_k${K}_$NAME.o terastructure_amd/csrc/tsamd_$U.hip &
+  NEW="$NEW $D/v_${U}_k${K}_$NAME.o"; SKIP="$SKIP|/${U}_k${K}\.o"
 fi
 if [ "$U" = all ]; then
   $CC "$@" -o $D/v_main_$NAME.o terastructure_amd/csrc/tsamd.hip &
