@@ -6,8 +6,8 @@
 // whole block and a location's inner loop depends on nothing but its own lambda.  Distinct locations are therefore
 // independent, and this kernel runs BX of them in lockstep:
 //   * the shard's weights sit in registers exactly as in ts_schedule (same launch geometry, same items per thread);
-//   * a pass sweeps them once per SUB-BATCH of BA locations (2 K BA accumulators per thread: 64 doubles at K <= 8),
-//     exp(Elogbeta) of the sub-batch's locations read from LDS at every use;
+//   * a pass sweeps them once per SUB-BATCH of BA locations (K = 8: two), whose 2 K BA accumulators and exp(Elogbeta)
+//     values sit in vector registers for the sweep (up to K = 24; read from LDS at every use above);
 //   * ONE in-launch exchange per pass carries the rows of all BX locations (up to 256 values, WideLay), and the BX
 //     K x 2 epilogues run side by side on BX * 2K lanes;
 //   * a location whose inner loop has ended (converged or the pass cap) is published and leaves the batch; the batch
@@ -24,8 +24,9 @@
 
 namespace tsamd {
 
-// locations whose accumulators a thread holds at once (2 K BA <= 64 doubles) ...
-constexpr int hol_sub(int k) { return k <= 8 ? 4 : k <= 10 ? 3 : k <= 16 ? 2 : 1; }
+// locations whose accumulators AND exp(Elogbeta) a thread holds at once (4 K BA <= 64 doubles: with the pairs re-read from
+// LDS per item and four locations' accumulators -- round 4's first form -- a sub-batch sweep took twice the instructions) ...
+constexpr int hol_sub(int k) { return k <= 4 ? 4 : k <= 8 ? 2 : 1; }
 // ... and locations per exchange: a multiple of that, at most 16, rows of at most 256 values (BX K <= 128)
 constexpr int hol_batch(int k) {
   const int ba = hol_sub(k);
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
   constexpr int BLOCK = 256, kWaves = BLOCK / 64, kItems = resident_items(KT);
   constexpr int BA = hol_sub(KT), BX = hol_batch(KT), NSUB = BX / BA, KX = BX * KT;
   constexpr uint32_t J = 2 * KT, JX = 2 * KX;
+  constexpr bool BS = KT <= 24;  // exp(Elogbeta) of the sub-batch's locations in vector registers for the sweep
   static_assert(resident_vec(KT) == 1, "one individual per item");
   static_assert(JX <= (uint32_t)BLOCK && BX <= 16 && BX % BA == 0, "a batch's row is brought by one thread per value");
   using Wide = WideLay<KX>;
@@ -184,13 +186,19 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
       for (int sub = 0; sub < NSUB; ++sub) {
         if (((active >> (uint32_t)(sub * BA)) & ((1u << BA) - 1u)) == 0u) continue;  // (uniform) nobody of this sub-batch runs any more
         fresh();
-        double acc0[BA][KT], acc1[BA][KT];
+        double acc0[BA][KT], acc1[BA][KT], b0[BA][BS ? KT : 1], b1[BA][BS ? KT : 1];
         uint32_t cd[BA];
 #pragma unroll
         for (int bb = 0; bb < BA; ++bb) {
           cd[bb] = s_codes[sub * BA + bb][tid];
 #pragma unroll
-          for (int k = 0; k < KT; ++k) acc0[bb][k] = acc1[bb][k] = 0.0;
+          for (int k = 0; k < KT; ++k) {
+            acc0[bb][k] = acc1[bb][k] = 0.0;
+            if constexpr (BS) {
+              b0[bb][k] = s_eb[sub * BA + bb][2 * k];
+              b1[bb][k] = s_eb[sub * BA + bb][2 * k + 1];
+            }
+          }
         }
 #pragma unroll
         for (int t = 0; t < kItems; ++t) {
@@ -198,13 +206,12 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
           double wcur[KT];
 #pragma unroll
           for (int k = 0; k < KT; ++k) wcur[k] = buf[t][k];
-          uint32_t zo = 0u;  // (opaque zero: exp(Elogbeta) is re-read from LDS per item instead of held in 4 K BA registers)
-          asm volatile("" : "+v"(zo));
-          const double d0[1] = {0.0}, d1[1] = {0.0};
+          uint32_t zo = 0u;  // (K > 24, opaque zero: exp(Elogbeta) is re-read from LDS per item instead of held in 4 K registers)
+          if constexpr (!BS) asm volatile("" : "+v"(zo));
 #pragma unroll
           for (int bb = 0; bb < BA; ++bb)
-            res_consume<KT, 1, false>(wcur, (cd[bb] >> (2u * (uint32_t)t)) & 3u, d0, d1,
-                                      reinterpret_cast<const double2 *>(&s_eb[sub * BA + bb][0]) + zo, acc0[bb], acc1[bb]);
+            res_consume<KT, 1, BS>(wcur, (cd[bb] >> (2u * (uint32_t)t)) & 3u, b0[bb], b1[bb],
+                                   reinterpret_cast<const double2 *>(&s_eb[sub * BA + bb][0]) + zo, acc0[bb], acc1[bb]);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll

@@ -1,4 +1,4 @@
-// ts_hybrid<K, WR>: a WHOLE schedule in one launch for shards ABOVE the register capacity of ts_schedule (gfx950).
+// ts_hybrid<K, WR, STREAM>: a WHOLE schedule in one launch for shards ABOVE the register capacity of ts_schedule (gfx950).
 //
 // ts_schedule (tsamd_resident_kernels.h) keeps the shard's N x K weights in the register file and gives up -- the
 // context drops to ten launches per update -- as soon as one individual more is asked for (K = 20: 327 680 per GPU).
@@ -58,7 +58,7 @@ __device__ __forceinline__ void hy_gamma_one(double (&gx)[KT], double (&wx)[KT],
   cn = ok ? cn + 1u : cn;
 }
 
-template <int KT, int WR>
+template <int KT, int WR, bool STREAM>
 __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
                                                     const uint32_t *sched, uint32_t n_sched, ResXchg *xb, uint32_t serial, const DevParams p) {
   constexpr int BLOCK = 256, kWaves = BLOCK / 64, R = hy_reg_items(KT), Q = hy_lds_items(KT), RQ = R + Q;
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
   // item t of the thread, or its last one, or -- a thread that owns none -- the shard's last item
   auto item_or_last = [&](uint32_t t) { return min(i0, nitems - 1u) + min(t, max(cnt, 1u) - 1u) * BLOCK; };
   const uint32_t cnt_wg = begin < end ? (end - begin + BLOCK - 1u) / BLOCK : 0u;  // items any thread of the workgroup owns (uniform)
-  const uint32_t scnt_wg = cnt_wg > (uint32_t)RQ ? cnt_wg - (uint32_t)RQ : 0u;   // ... of which streamed
+  // ... of which streamed (STREAM = false: the host has checked that there are none; the streamed code is compiled out)
+  const uint32_t scnt_wg = (STREAM && cnt_wg > (uint32_t)RQ) ? cnt_wg - (uint32_t)RQ : 0u;
   const uint32_t g = blockIdx.x % (uint32_t)kResGroups, m = blockIdx.x / (uint32_t)kResGroups;
 
   if (__hip_atomic_load(&xb->abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return;  // (see ts_resident)
@@ -215,12 +216,15 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
     const uint32_t i = item_or_last((uint32_t)RQ + s);
     return (uint32_t)RQ + s < cnt ? (word >> (2u * (i % 16u))) & 3u : 1u;
   };
+  // The streamed items of a pass go through two buffers, one item ahead.  The FIRST item of a pass is requested ahead of the
+  // pass: for a SNP's first pass right after the gamma step (which changes the weights), for every later one while the
+  // workgroup waits in the exchange (res_exchange's overlap hook: the weights do not change between the passes of a SNP,
+  // and the memory system idles there otherwise).  One buffer only is in flight across the exchange: with both, the
+  // register items' sweep no longer fits the register file.
+  double sa[KT], sbuf[KT];
+  uint32_t worda = 0u, wordb = 0u;
+  auto request_first = [&]() { load_streamed(0u, sa, worda); };
   auto sweep = [&]() {
-    // the first streamed item is requested before the register items are swept: its latency hides behind them
-    double sa[KT], sbuf[KT];
-    uint32_t worda = 0u, wordb = 0u;
-    if (scnt_wg > 0u) load_streamed(0u, sa, worda);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       if ((uint32_t)t >= cnt_wg) continue;
@@ -241,8 +245,9 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
       consume(wcur, (codes2 >> (2u * (uint32_t)q)) & 3u);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // streamed items: two-stage software pipeline, two items per turn (no register moves between the stages)
-    for (uint32_t s = 0; s < scnt_wg; s += 2u) {
+    // streamed items: two-stage software pipeline, two items per turn (no register moves between the stages; clamped
+    // requests: static load counts)
+    for (uint32_t s = 0; STREAM && s < scnt_wg; s += 2u) {
       fresh();
       load_streamed(s + 1u, sbuf, wordb);
       __builtin_amdgcn_sched_barrier(0);
@@ -271,7 +276,15 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
     }
     xcount += 1u;
     const uint32_t tag = xseq0 + xcount;
-    if (!res_exchange<KT, WR>(xb, p, tag, 1u, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial), kResWaitTicks)) return false;
+    // (under the pass cap this may be the SNP's last pass: then the next sweep follows a gamma step and requests afresh)
+    const bool ahead = STREAM && iters < p.max_inner;
+    auto overlap = [&]() {
+      if constexpr (STREAM)
+        if (ahead) request_first();
+    };
+    if (!res_exchange<KT, WR, kResOneLevelGrid, ResLay<KT>>(xb, p, tag, 1u, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial),
+                                                            kResWaitTicks, overlap))
+      return false;
     TSAMD_HK(tk_xchg);
     if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);
     __syncthreads();
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (scnt_wg > 0u) {
+      if (STREAM && scnt_wg > 0u) {
         double wsn[KT];
         uint32_t pwn = 0u;
         auto load_sitem = [&](uint32_t s) {
@@ -384,11 +397,12 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
       w_dirty = true;
     }
     col = reinterpret_cast<const uint32_t *>(p.bed + (size_t)loc * p.colstride);
+    if constexpr (STREAM) request_first();  // (the first pass' first streamed item: its latency hides behind the other items' sweep)
     __syncthreads();
     TSAMD_HK(tk_gamma);
     // ---- the passes of the new SNP ------------------------------------------------------------------------------
     complete = false;
-    while (!complete) {
+    while (!complete) {  // (a pass that follows another: the pass cap was not reached, so the exchange's overlap hook has requested its first streamed item)
       begin_pass();
       sweep();
       TSAMD_HK(tk_sweep);

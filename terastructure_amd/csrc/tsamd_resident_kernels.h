@@ -192,10 +192,16 @@ __device__ __forceinline__ void res_post(unsigned long long *dst, uint32_t tag, 
 // wider rows -- LAY = WideLay -- have one region only).  On return (after a
 // workgroup barrier) s_tot[0][j] holds the region-A totals in every workgroup and s_tot[1][j] the region-B totals in
 // workgroup 0.  WR: row pairs per lane of the cross-rank level 2 (0: one GPU).  false: a bounded wait gave up.
-template <int KT, int WR, int ONE = kResOneLevelGrid, class LAY = ResLay<KT>>
+// `overlap` is called exactly once by every thread, at the point where the workgroup has nothing to do but wait: a member
+// right after it has posted its row, a leader after it has published its group's sum (its level-1 sweep is on everybody's
+// critical path).  ts_hybrid requests the next pass' first streamed items there: the loads travel while the sums do.
+struct NoOverlap {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int KT, int WR, int ONE = kResOneLevelGrid, class LAY = ResLay<KT>, class OV = NoOverlap>
 __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, uint32_t tag, uint32_t width, double mine, uint32_t g, uint32_t m,
                                              uint32_t grid, double *s_tot /* [2][2K] */, int *s_alive /* [4], all 1 */, uint32_t tid,
-                                             unsigned long long code, unsigned long long ticks) {
+                                             unsigned long long code, unsigned long long ticks, OV overlap = OV()) {
   using L = LAY;
   constexpr uint32_t J = 2 * KT, RB = (uint32_t)res_blocks(KT), GR = L::GR;
   constexpr int kPerWave = (2 * (int)RB + 3) / 4;  // column blocks a wave sweeps at most
@@ -206,6 +212,7 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
     if (grid == 1u) {  // ONE workgroup (the smallest cohorts): its row is the total, nothing goes through memory
       const uint32_t region = kWideRow ? 0u : tid >> 6, j = kWideRow ? tid : tid & 63u;
       if (region < width && j < J) s_tot[region * J + j] = mine;
+      overlap();
       __syncthreads();
       return true;
     }
@@ -221,6 +228,7 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
         const uint32_t region = kWideRow ? 0u : tid >> 6, j = kWideRow ? tid : tid & 63u;
         if (region < width && j < J) res_post(L::flat(xb, region, slot, blockIdx.x) + 2u * j, tag, mine, 0);
       }
+      overlap();
       bool alive1 = true;
 #pragma unroll
       for (int u = 0; u < kPerWave; ++u) {
@@ -251,6 +259,7 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
     const uint32_t region = kWideRow ? 0u : tid >> 6, j = kWideRow ? tid : tid & 63u;
     if (region < width && j < J) res_post(L::rows(xb, region, g, m) + 2u * j, tag, mine, 0);
   }
+  if (m != 0u) overlap();
   const uint32_t members = g < grid ? (grid - g + (uint32_t)kResGroups - 1u) / (uint32_t)kResGroups : 0u;
   const uint32_t groups = min(grid, (uint32_t)kResGroups);
   bool alive = true;
@@ -275,6 +284,7 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
         }
       }
     }
+    overlap();
   }
   // level 2: region A everybody, region B workgroup 0 only
 #pragma unroll
