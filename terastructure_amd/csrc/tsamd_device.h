@@ -353,11 +353,14 @@ struct WaveFold {
 // PLINK 2-bit code -> (weight of the "mom" copy = y, weight of the "dad" copy = 2 - y);
 // 01 (missing, or held out) -> (0, 0).  src/snp.cc:203-216, src/snpsamplinge.cc:755-756.
 __device__ __forceinline__ void code_weights(uint32_t c, double &mom, double &dad, bool &ok) {
+  // (all integer arithmetic, no select: a v_cndmask on vcc costs a resident kernel's lone wave four times an integer
+  // instruction, tools/ubench/op_cost.hip -- and this runs once per individual and pass)
   const uint32_t hi = c >> 1, lo = c & 1u;
-  ok = !(hi == 0u && lo == 1u);
-  const uint32_t y = hi * (1u + lo);
+  const uint32_t miss = lo & (hi ^ 1u);  // 01
+  ok = miss == 0u;
+  const uint32_t y = hi * (1u + lo);     // 00 -> 0, 10 -> 1, 11 -> 2 (01 -> 0)
   mom = (double)y;
-  dad = ok ? (double)(2u - y) : 0.0;
+  dad = (double)(2u - y - 2u * miss);    // 2 - y, and 0 for a missing genotype (y = 0 there)
 }
 
 // wave-uniform double -> scalar registers (frees VGPRs; v_fma_f64 takes one SGPR pair)

@@ -157,6 +157,45 @@ __device__ __forceinline__ bool res_sweep(const unsigned long long *base, uint32
   }
 }
 
+// The same for NB column blocks of the same rows in ONE poll (wide rows, ts_holblock: a wave sweeps blocks first, first + 4,
+// ... of a row of gran_total granules): the blocks of a row are posted together, so one memory round trip serves them all
+// where NB consecutive res_sweep calls take NB.  Blocks past nblk do not exist (their loads are clamped and ignored).
+template <int N, int NB, int SCOPE>
+__device__ __forceinline__ bool res_sweep_blocks(const unsigned long long *base, uint32_t stride, uint32_t first, uint32_t nblk, uint32_t gran_total,
+                                                 uint32_t tag, uint32_t row_limit, unsigned (&v)[NB][N], unsigned long long *abort_word,
+                                                 unsigned long long *host_flag, unsigned long long code, unsigned long long ticks, uint32_t lane) {
+  const uint32_t c = lane & 31u;
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const uint32_t q = first + 4u * (uint32_t)u, qc = min(q, nblk - 1u);
+      const uint32_t nvalid = q < nblk ? min(32u, gran_total - 32u * q) : 0u;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const uint32_t row = 2u * (uint32_t)i + (lane >> 5);
+        const bool exists = c < nvalid && row < row_limit;
+        const unsigned long long x = __hip_atomic_load(base + (size_t)row * stride + 32u * qc + c, __ATOMIC_RELAXED, SCOPE);
+        v[u][i] = exists ? (unsigned)x : 0u;
+        ok &= !exists || (unsigned)(x >> 32) == tag;
+      }
+    }
+    if (__all(ok)) return true;
+    if (wall_clock64() - t0 > ticks || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
+      if (lane == 0) {
+        __hip_atomic_store(abort_word, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (host_flag) {
+          if ((code & kFailIntact) == 0ull) __hip_atomic_store(host_flag + kHostDirtyWord, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(host_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 // sum of the N row pairs a wave has swept (lo / hi halves of a double sit in neighbouring lanes): on return lane 2 j
 // (j < 16) holds the total of value j of the block over rows 0, 2, 4, ... plus rows 1, 3, 5, ...  All on the vector
 // ALU: the partner's half comes over DPP (quad_perm), the other half-wave's sum over v_permlane32_swap -- through the
@@ -230,6 +269,31 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
       }
       overlap();
       bool alive1 = true;
+      if constexpr (kWideRow) {
+        // a wide row (ts_holblock): all of this wave's column blocks in one poll
+        constexpr int NBW = ((int)RB + 3) / 4;
+        auto sweep_all = [&](auto n_c) {
+          constexpr int N = decltype(n_c)::value;
+          constexpr int NBP = N > 8 ? 2 : 4;  // blocks per poll (16 row pairs x 2 blocks = 64 loads in flight per lane)
+#pragma unroll
+          for (int u0 = 0; u0 < NBW; u0 += NBP) {
+            if (wave + 4u * (uint32_t)u0 >= RB) break;
+            unsigned v[NBP][N];
+            alive1 = res_sweep_blocks<N, NBP, __HIP_MEMORY_SCOPE_AGENT>(L::flat(xb, 0u, slot, 0), GR, wave + 4u * (uint32_t)u0, RB, 2u * J, tag, grid, v,
+                                                                       &xb->abort_word, p.host_error, code, ticks, lane) && alive1;
+#pragma unroll
+            for (int u = 0; u < NBP; ++u) {
+              const uint32_t q = wave + 4u * (uint32_t)(u0 + u);
+              if (q < RB) {
+                const uint32_t nvalid = min(32u, 2u * J - 32u * q);
+                const double sv = res_sum<N>(v[u], lane);
+                if (lane < nvalid && !(lane & 1u)) s_tot[16u * q + (lane >> 1)] = sv;
+              }
+            }
+          }
+        };
+        if (ONE <= 16 || grid <= 16u) sweep_all(std::integral_constant<int, 8>{}); else sweep_all(std::integral_constant<int, (ONE > 16 ? ONE / 2 : 8)>{});
+      } else {
 #pragma unroll
       for (int u = 0; u < kPerWave; ++u) {
         const uint32_t q = wave + 4u * (uint32_t)u;
@@ -250,6 +314,7 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
           if (lane < nvalid && !(lane & 1u)) s_tot[region * J + 16u * cb + (lane >> 1)] = s;
         }
       }
+      }
       if (lane == 0 && !alive1) s_alive[wave] = 0;
       __syncthreads();
       return (s_alive[0] & s_alive[1] & s_alive[2] & s_alive[3]) != 0;
@@ -265,6 +330,25 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
   bool alive = true;
   // level 1 (leaders): all of this wave's blocks first, so that every group sum is on its way before anybody waits for one
   if (m == 0) {
+    if constexpr (kWideRow && WR == 0) {
+      constexpr int NBW = ((int)RB + 3) / 4, NBP = 2;  // two blocks per poll: 16 row pairs x 2 = 64 loads in flight per lane
+#pragma unroll
+      for (int u0 = 0; u0 < NBW; u0 += NBP) {
+        if (wave + 4u * (uint32_t)u0 >= RB) break;
+        unsigned v[NBP][kResMembers / 2];
+        alive = res_sweep_blocks<kResMembers / 2, NBP, __HIP_MEMORY_SCOPE_AGENT>(L::rows(xb, 0u, g, 0), GR, wave + 4u * (uint32_t)u0, RB, 2u * J, tag, members,
+                                                                                v, &xb->abort_word, p.host_error, code, ticks, lane) && alive;
+#pragma unroll
+        for (int u = 0; u < NBP; ++u) {
+          const uint32_t q = wave + 4u * (uint32_t)(u0 + u);
+          if (q < RB) {
+            const uint32_t nvalid = min(32u, 2u * J - 32u * q);
+            const double sv = res_sum<kResMembers / 2>(v[u], lane);
+            if (lane < nvalid && !(lane & 1u)) res_post(L::sums(xb, 0u, tag & 1u, g) + 32u * q + lane, tag, sv, 0);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int u = 0; u < kPerWave; ++u) {
       const uint32_t q = wave + 4u * (uint32_t)u;
@@ -284,9 +368,25 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
         }
       }
     }
+    }
     overlap();
   }
   // level 2: region A everybody, region B workgroup 0 only
+  if constexpr (kWideRow && WR == 0) {
+    constexpr int NBW = ((int)RB + 3) / 4;
+    unsigned v2[NBW][kResGroups / 2];
+    alive = res_sweep_blocks<kResGroups / 2, NBW, __HIP_MEMORY_SCOPE_AGENT>(L::sums(xb, 0u, tag & 1u, 0), GR, wave, RB, 2u * J, tag, groups, v2,
+                                                                           &xb->abort_word, p.host_error, code, ticks, lane) && alive;
+#pragma unroll
+    for (int u = 0; u < NBW; ++u) {
+      const uint32_t q = wave + 4u * (uint32_t)u;
+      if (q < RB) {
+        const uint32_t nvalid = min(32u, 2u * J - 32u * q);
+        const double sv = res_sum<kResGroups / 2>(v2[u], lane);
+        if (lane < nvalid && !(lane & 1u)) s_tot[16u * q + (lane >> 1)] = sv;
+      }
+    }
+  } else {
 #pragma unroll
   for (int u = 0; u < kPerWave; ++u) {
     const uint32_t q = wave + 4u * (uint32_t)u;
@@ -315,6 +415,7 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
       }
       if (lane < nvalid && !(lane & 1u)) s_tot[region * J + 16u * cb + (lane >> 1)] = s;
     }
+  }
   }
   if (lane == 0 && !alive) s_alive[wave] = 0;
   __syncthreads();
