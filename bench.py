@@ -167,6 +167,13 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
             if mode.startswith("p2p_schedule") and not whole:
                 report["valid"].pop(mode)
                 continue                                       # the shards do not qualify: not a candidate
+            if mode.startswith("p2p_schedule"):
+                # which whole-schedule kernel the ranks run: ts_schedule (the shard's weights fit the register file) or, above
+                # that capacity, ts_hybrid (registers + LDS + streamed weights; up to 4 ranks) -- the same on every rank
+                geo = e.schedule_geometry()
+                report.setdefault("schedule_kernel", {})[mode] = (
+                    f"ts_hybrid<{k}> ({geo['on_chip_per_thread']} of {geo['indivs_per_thread']} individuals per thread on chip)"
+                    if geo["indivs_per_thread"] > resident_geometry(k)[1] else f"ts_schedule<{k}> ({geo['indivs_per_thread']} individuals per thread)")
             if want is None:  # the oracle's answer for the first 6 updates, once, on rank 0
                 ok, cols, err = step(lambda: np.stack([e.download_bed(j) for j in range(l)]))          # [l][shard bytes]
                 if not ok:
@@ -630,6 +637,39 @@ def main():
                       "first_pass": None if per_snp is None else per_snp["first_pass"],
                       "probe_read_us": None if read_us is None else round(read_us, 3),
                   }
+              # A shard above ts_schedule's register capacity runs the same one-launch structure as ts_hybrid: part of the
+              # weights in registers + LDS, the rest re-read from memory every pass, all of gamma streamed -- that kernel is
+              # bound by memory, and priced so: the bytes it must move by construction over the launch time against the HBM peak.
+              try:
+                  geo = eng.schedule_geometry()
+              except Exception:  # noqa: BLE001
+                  geo = None
+              if roofline is not None and roofline.get("bound") == "fp64_valu" and geo and geo["indivs_per_thread"] > resident_geometry(k)[1]:
+                  on_chip = min(sc, geo["workgroups"] * 256 * geo["on_chip_per_thread"])
+                  streamed = sc - on_chip
+                  ppu_ = roofline["passes_per_update"]
+                  upd_ = roofline["updates_per_launch"]
+                  launch_s_ = roofline["avg_launch_us"] * 1e-6
+                  moved_h = ppu_ * streamed * 8.0 * k + sc * (16.0 * k + 8.0) + streamed * 16.0 * k + (ppu_ + 1.0) * sc / 4.0
+                  fp64 = {key: roofline[key] for key in ("achieved", "peak", "unit", "frac", "flops_per_update", "flops_per_update_hand_count",
+                                                         "flops_source")}
+                  fp64["bound"] = "fp64_valu"
+                  roofline.update({
+                      "bound": "hbm",
+                      "kernel": (f"ts_hybrid<{k}> (one launch = {upd_:.0f} SNP updates; of a thread's {geo['indivs_per_thread']} individuals "
+                                 f"{geo['on_chip_per_thread']} keep their weights in registers + LDS for the whole launch, the weights of the "
+                                 "others are re-read every pass; gamma and c_n of all stream through the gamma step)"),
+                      "achieved": round(moved_h * upd_ / launch_s_ / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(moved_h * upd_ / launch_s_ / 1e9 / HBM_PEAK_GBS, 4),
+                      "algorithmic_bytes_per_update": moved_h,
+                      "algorithmic_bytes_note": ("passes x streamed individuals x 8K (weights re-read) + N (16K + 8) (gamma, c_n read and written) + "
+                                                 "streamed x 16K (their weights read and written by the gamma step) + (passes + 1) N / 4 (columns)"),
+                      "streamed_individuals": int(streamed), "on_chip_individuals": int(on_chip),
+                      "fp64_valu": fp64,
+                      "bound_note": ("memory: the streamed weights (Infinity Cache / HBM) and the gamma step's streams; the exchanges and epilogues "
+                                     "(`latency`) run with the memory system idle"),
+                  })
+                  roofline["traffic"] = None if not rec.get("hbm_bytes_per_update") else rec["hbm_bytes_per_update"] * upd_
           else:
               roofline = per_snp
           if roofline is not None:

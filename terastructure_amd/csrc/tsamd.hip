@@ -1430,6 +1430,10 @@ static int settle(tsamd_ctx *c) {
     // (a workgroup that passed the entry exchange, modified state and only then met the abort word leaves its code here:
     // the launch did NOT give up as a whole with its state intact, whatever the first word says)
     const bool dirty = *(volatile unsigned long long *)(c->h_error + kHostDirtyWord) != 0ull;
+    if (getenv("TSAMD_DEBUG"))
+      fprintf(stderr, "[tsamd rank %u] settle: error word %llx (tag %llu, intact %d, parity %d, serial %llu), modified-state word %llx, journal %zu, "
+              "launch serial %u, mode %d/%d\n", c->cfg.rank, err, tag, (int)((err & kFailIntact) != 0ull), (int)((err >> 33) & 1ull), err >> 34,
+              *(volatile unsigned long long *)(c->h_error + kHostDirtyWord), c->journal.size(), c->launch_serial, (int)c->resident, (int)c->persistent);
     // (a sharded context, one process per rank: the entry exchange spans the ranks, so it fails on EVERY rank -- nobody has
     // written anything -- and every rank, driven by the same calls, finds the same launch in its journal and replays the
     // same kernels.  Contexts of ONE process (tsamd_p2p_connect_local) are settled one after the other and would wait for
@@ -1438,8 +1442,9 @@ static int settle(tsamd_ctx *c) {
       rc = recover_from_failed_entry(c, err);
     else if (c->p2p && (c->persistent || (err & kFailIntact) != 0ull))
       rc = fail(c, TSAMD_ECOMM, "ts_schedule: the in-launch exchange across %u ranks timed out (tag %llu): a peer did not arrive, or "
-                "not all workgroups of all ranks are resident (ranks that share one device: TSAMD_DEVICE_SHARE=<ranks>)",
-                c->cfg.world, tag);
+                "not all workgroups of all ranks are resident (ranks that share one device: TSAMD_DEVICE_SHARE=<ranks>) [code %llx, "
+                "modified-state word %llx, whole-schedule mode %d, mapped peers %zu]",
+                c->cfg.world, tag, err, *(volatile unsigned long long *)(c->h_error + kHostDirtyWord), (int)c->persistent, c->peer_maps.size());
     else if (c->p2p)
       rc = fail(c, TSAMD_ECOMM, "peer-to-peer exchange timed out waiting for a peer (epoch %llu)", err);
     else if (tag == 0xffffffffull)

@@ -35,7 +35,7 @@ constexpr int hol_batch(int k) {
   if (n < 1) n = 1;
   return n * ba;
 }
-constexpr uint32_t kHolChunk = 1u << 14;  // locations per launch at most (every in-kernel wait is bounded)
+constexpr uint32_t kHolChunk = 1u << 14;
 
 template <int KT>
 __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
@@ -51,7 +51,11 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
   __shared__ double s_diff[BX][J];
   __shared__ double s_tot[JX > 4 * J ? JX : 4 * J];
   __shared__ double s_red[BX][kWaves][J];
-  __shared__ uint32_t s_codes[BX][BLOCK];  // the items' 2-bit codes of the batch's columns, packed per thread
+  // the items' genotype factors of the batch's columns, decoded ONCE per batch and packed per thread: item t holds the
+  // nibble (y, 2 - y) -- (0, 0) for a missing, held-out or unowned genotype -- in bits 4t .. 4t+3.  A sweep then spends two
+  // bit-field extracts and two conversions per individual where code_weights spends ten instructions (as ts_schedule does
+  // per SNP: code_nibble / res_consume_md, tsamd_resident_kernels.h).
+  __shared__ uint2 s_codes[BX][BLOCK];
   __shared__ int s_alive[4];
 
   const uint32_t par = par_arg & 1u;
@@ -162,14 +166,14 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
 #pragma unroll
       for (int bb = 0; bb < BA; ++bb) {
         const uint32_t b = (uint32_t)(sub * BA + bb);
-        uint32_t out = 0u;
+        uint32_t out[2] = {0u, 0u};
 #pragma unroll
         for (int t = 0; t < kItems; ++t) {
           const uint32_t i = item_or_last((uint32_t)t);
           const uint32_t c = ((uint32_t)t < cnt && b < nb) ? (word[bb][t] >> (2u * (i % 16u))) & 3u : 1u;
-          out |= c << (2u * (uint32_t)t);
+          out[t / 8] |= code_nibble(c) << (4u * (uint32_t)(t % 8));
         }
-        s_codes[b][tid] = out;
+        s_codes[b][tid] = make_uint2(out[0], out[1]);
       }
     }
     uint32_t active = nb >= 32u ? 0xffffffffu : (1u << nb) - 1u;  // (uniform) locations of the batch whose inner loop still runs
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
         if (((active >> (uint32_t)(sub * BA)) & ((1u << BA) - 1u)) == 0u) continue;  // (uniform) nobody of this sub-batch runs any more
         fresh();
         double acc0[BA][KT], acc1[BA][KT], b0[BA][BS ? KT : 1], b1[BA][BS ? KT : 1];
-        uint32_t cd[BA];
+        uint2 cd[BA];
 #pragma unroll
         for (int bb = 0; bb < BA; ++bb) {
           cd[bb] = s_codes[sub * BA + bb][tid];
@@ -209,9 +213,11 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
           uint32_t zo = 0u;  // (K > 24, opaque zero: exp(Elogbeta) is re-read from LDS per item instead of held in 4 K registers)
           if constexpr (!BS) asm volatile("" : "+v"(zo));
 #pragma unroll
-          for (int bb = 0; bb < BA; ++bb)
-            res_consume<KT, 1, BS>(wcur, (cd[bb] >> (2u * (uint32_t)t)) & 3u, b0[bb], b1[bb],
-                                   reinterpret_cast<const double2 *>(&s_eb[sub * BA + bb][0]) + zo, acc0[bb], acc1[bb]);
+          for (int bb = 0; bb < BA; ++bb) {
+            const uint32_t nib = nibble_of(cd[bb], t);
+            res_consume_md<KT, BS>(wcur, (double)(nib & 3u), (double)(nib >> 2), b0[bb], b1[bb],
+                                reinterpret_cast<const double2 *>(&s_eb[sub * BA + bb][0]) + zo, acc0[bb], acc1[bb]);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll

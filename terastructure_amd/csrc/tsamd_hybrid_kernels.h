@@ -36,10 +36,10 @@ constexpr int kHybridMaxStreamed = 64;
 // weights -- ts_schedule's lean form: (1 - rho) gamma + rho alpha + w_k (c0 sb_k0 + c1 sb_k1), rho * scale folded into
 // c0 / c1, ONE reciprocal for both parents; an unobserved genotype takes the same instructions with a step of exactly 0.
 template <int KT>
-__device__ __forceinline__ void hy_gamma_one(double (&gx)[KT], double (&wx)[KT], uint32_t code2, uint32_t &cn, const double *s_sb, const DevParams &p) {
-  double mom, dad;
-  bool ok;
-  code_weights(code2 & 3u, mom, dad, ok);
+__device__ __forceinline__ void hy_gamma_one(double (&gx)[KT], double (&wx)[KT], uint32_t nib, uint32_t &cn, const double *s_sb, const DevParams &p) {
+  // (nib: the genotype's factors (y, 2 - y) as code_nibble packs them; 0 when unobserved)
+  const double mom = (double)(nib & 3u), dad = (double)((nib >> 2) & 3u);
+  const bool ok = (nib & 15u) != 0u;
   double s0 = 0.0, s1 = 0.0;
   uint32_t zo = 0u;  // (opaque zero: exp(Elogbeta) is re-read from LDS where it is used, not held in 4K registers)
   asm volatile("" : "+v"(zo));
@@ -122,27 +122,27 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
 #pragma unroll
     for (int k = 0; k < KT; ++k) s_w[q][k][tid] = (w_a + (size_t)k * np)[i];
   }
-  // the 2-bit codes of a column for this thread's register items (FIRST = 0, N = R) or LDS items (FIRST = R, N = Q),
-  // packed into one register; an item the thread does not own: missing
-  auto load_codes = [&](uint32_t loc_, auto first_c, auto n_c) -> uint32_t {
+  // the genotypes of a column for this thread's register items (FIRST = 0, N = R) or LDS items (FIRST = R, N = Q), decoded
+  // once per SNP into nibbles (code_nibble: (y, 2 - y), 0 when unobserved or not owned) and packed into two registers
+  auto load_codes = [&](uint32_t loc_, auto first_c, auto n_c) -> uint2 {
     constexpr int FIRST = decltype(first_c)::value, N = decltype(n_c)::value;
     const uint32_t *col = reinterpret_cast<const uint32_t *>(p.bed + (size_t)loc_ * p.colstride);
     uint32_t word[N];
 #pragma unroll
     for (int t = 0; t < N; ++t) word[t] = col[item_or_last((uint32_t)(FIRST + t)) / 16u];
-    uint32_t out = 0u;
+    uint32_t out[2] = {0u, 0u};
 #pragma unroll
     for (int t = 0; t < N; ++t) {
       const uint32_t i = item_or_last((uint32_t)(FIRST + t));
       const uint32_t c = (uint32_t)(FIRST + t) < cnt ? (word[t] >> (2u * (i % 16u))) & 3u : 1u;
-      out |= c << (2u * (uint32_t)t);
+      out[t / 8] |= code_nibble(c) << (4u * (uint32_t)(t % 8));
     }
-    return out;
+    return make_uint2(out[0], out[1]);
   };
   using IC0 = std::integral_constant<int, 0>;
   using ICR = std::integral_constant<int, R>;
   using ICQ = std::integral_constant<int, Q>;
-  uint32_t pcodes = svalid ? load_codes(sloc, IC0{}, ICR{}) : 0x55555555u, pcodes2 = svalid ? load_codes(sloc, ICR{}, ICQ{}) : 0x55555555u;
+  uint2 pcodes = svalid ? load_codes(sloc, IC0{}, ICR{}) : make_uint2(0u, 0u), pcodes2 = svalid ? load_codes(sloc, ICR{}, ICQ{}) : make_uint2(0u, 0u);
   if (tid < J) {
     s_sb[tid] = S->eb[tid];
     s_plam[tid] = svalid ? p.lam[(size_t)sloc * J + tid] : 0.0;
@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
   double lam_old = 0.0, eb_used = 0.0;
   double b0[BS ? KT : 1], b1[BS ? KT : 1], acc0[KT], acc1[KT];
   bool complete = false;
-  uint32_t codes = 0u, codes2 = 0u, loc = 0u, hol = 0u;
+  uint2 codes = make_uint2(0u, 0u), codes2 = make_uint2(0u, 0u);
+  uint32_t loc = 0u, hol = 0u;
   const uint32_t *col = nullptr;  // the running SNP's column (streamed items take their codes from it per pass)
 
   auto begin_pass = [&]() {
@@ -200,10 +201,10 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
       acc0[k] = acc1[k] = 0.0;
     }
   };
-  auto consume = [&](const double (&wcur)[KT], uint32_t code) {
+  auto consume = [&](const double (&wcur)[KT], uint32_t nib) {
     uint32_t zo = 0u;  // (opaque zero: the LDS reads of exp(Elogbeta) are repeated per item instead of held in 4K registers)
     if constexpr (!BS) asm volatile("" : "+v"(zo));
-    res_consume<KT, 1, BS>(wcur, code, b0, b1, reinterpret_cast<const double2 *>(s_eb) + zo, acc0, acc1);
+    res_consume_md<KT, BS>(wcur, (double)(nib & 3u), (double)(nib >> 2), b0, b1, reinterpret_cast<const double2 *>(s_eb) + zo, acc0, acc1);
   };
   // a streamed item's rows and its word of the column, from memory (clamped: static load counts)
   auto load_streamed = [&](uint32_t s, double (&wv)[KT], uint32_t &word) {
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
   };
   auto streamed_code = [&](uint32_t s, uint32_t word) -> uint32_t {
     const uint32_t i = item_or_last((uint32_t)RQ + s);
-    return (uint32_t)RQ + s < cnt ? (word >> (2u * (i % 16u))) & 3u : 1u;
+    return code_nibble((uint32_t)RQ + s < cnt ? (word >> (2u * (i % 16u))) & 3u : 1u);
   };
   // The streamed items of a pass go through two buffers, one item ahead.  The FIRST item of a pass is requested ahead of the
   // pass: for a SNP's first pass right after the gamma step (which changes the weights), for every later one while the
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
       double wcur[KT];
 #pragma unroll
       for (int k = 0; k < KT; ++k) wcur[k] = buf[t][k];
-      consume(wcur, (codes >> (2u * (uint32_t)t)) & 3u);
+      consume(wcur, nibble_of(codes, t));
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
       double wcur[KT];
 #pragma unroll
       for (int k = 0; k < KT; ++k) wcur[k] = s_w[q][k][tid];
-      consume(wcur, (codes2 >> (2u * (uint32_t)q)) & 3u);
+      consume(wcur, nibble_of(codes2, q));
       __builtin_amdgcn_sched_barrier(0);
     }
     // streamed items: two-stage software pipeline, two items per turn (no register moves between the stages; clamped
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
 #pragma unroll
           for (int k = 0; k < KT; ++k) wcur[k] = s_w[t < R ? 0 : t - R][k][tid];
         }
-        const uint32_t pcode = t < R ? (pcodes >> (2u * (uint32_t)t)) & 3u : (pcodes2 >> (2u * (uint32_t)(t - R))) & 3u;
+        const uint32_t pcode = t < R ? nibble_of(pcodes, t < R ? t : 0) : nibble_of(pcodes2, t < R ? 0 : t - R);
         hy_gamma_one<KT>(gv, wcur, pcode, cv, s_sb, p);
         if ((uint32_t)t < cnt) store_gamma(i, gv, cv);
         if (t < R) {
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
           }
           load_sitem(min(s + 1u, scnt_wg - 1u));
           __builtin_amdgcn_sched_barrier(0);
-          const uint32_t pcode = (uint32_t)RQ + s < cnt ? (pw >> (2u * (i % 16u))) & 3u : 1u;
+          const uint32_t pcode = code_nibble((uint32_t)RQ + s < cnt ? (pw >> (2u * (i % 16u))) & 3u : 1u);
           hy_gamma_one<KT>(gv, wcur, pcode, cv, s_sb, p);
           if ((uint32_t)RQ + s < cnt) {
             store_gamma(i, gv, cv);

@@ -495,6 +495,42 @@ __device__ __forceinline__ void res_consume(const typename Lanes<VEC>::T (&wv)[K
   }
 }
 
+// The same for ONE individual whose genotype factors (y, 2 - y; both 0 when unobserved) are already decoded: the same
+// instructions on the same values in the same order as res_consume<KT, 1, BS> -- the same bits.  ts_schedule and
+// ts_holblock decode a column once per SNP / batch into nibbles (pack_nibbles) instead of once per individual and pass.
+template <int KT, bool BS>
+__device__ __forceinline__ void res_consume_md(const double (&wv)[KT], double mom, double dad, const double (&b0)[BS ? KT : 1],
+                                               const double (&b1)[BS ? KT : 1], const double2 *s_b, double (&acc0)[KT], double (&acc1)[KT]) {
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    if constexpr (BS) {
+      s0 = fma(wv[k], b0[k], s0);
+      s1 = fma(wv[k], b1[k], s1);
+    } else {
+      const double2 b = s_b[k];
+      s0 = fma(wv[k], b.x, s0);
+      s1 = fma(wv[k], b.y, s1);
+    }
+  }
+  const double inv = fast_rcp(s0 * s1);
+  const double c0 = (mom * s1) * inv, c1 = (dad * s0) * inv;
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    acc0[k] = fma(c0, wv[k], acc0[k]);
+    acc1[k] = fma(c1, wv[k], acc1[k]);
+  }
+}
+// PLINK 2-bit code -> nibble (y, 2 - y) in bits 0-1 / 2-3; 0 for a missing (or held-out, or unowned) genotype
+__device__ __forceinline__ uint32_t code_nibble(uint32_t c) {
+  const uint32_t hi = c >> 1, lo = c & 1u, miss = lo & (hi ^ 1u), y = hi * (1u + lo);  // (code_weights, tsamd_device.h)
+  return y | ((2u - y - 2u * miss) << 2);
+}
+// nibble t of a thread's packed items (x: items 0 .. 7, y: items 8 .. 15; t is a constant after unrolling)
+__device__ __forceinline__ uint32_t nibble_of(const uint2 &c, int t) {
+  return ((t < 8 ? c.x : c.y) >> (4 * (t % 8))) & 15u;
+}
+
 // workgroup reduction of the 2K accumulators, fixed order: lanes (halving butterfly) -> s_red[wave][value]
 template <int KT>
 __device__ __forceinline__ void res_fold(const double (&acc0)[KT], const double (&acc1)[KT], double *s_red /* [4][2K] */, uint32_t tid) {
@@ -750,7 +786,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   using CT = typename LN::C;
   using RC = ResCodes<VEC>;
   constexpr uint32_t J = 2 * KT;
-  static_assert(kItems * RC::kCodeBits <= 32, "the items' codes are packed into one register");
+  static_assert(VEC == 1 && kItems <= 16, "one individual per item; the items' genotype nibbles are packed into two registers");
   __shared__ __attribute__((aligned(16))) double s_eb[J];
   __shared__ __attribute__((aligned(16))) double s_sb[J];
   __shared__ double s_lam[J], s_diff[J], s_tot[2 * J], s_plam[J], s_peb[J];
@@ -852,32 +888,34 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     for (int k = 0; k < KT; ++k) s_gam[lds_slot(t)][k][tid] = gv[k];
     s_cn[lds_slot(t)][tid] = cv;
   };
-  // the 2-bit codes of a column for this thread's items, packed into one register (an item the thread does not own:
-  // missing).  In two steps, so that the words of the NEXT SNP's column can be requested a SNP ahead and packed when
-  // they are needed.
+  // the genotypes of a column for this thread's items, decoded once per SNP into nibbles (y, 2 - y; 0 for a missing or
+  // held-out genotype and for an item the thread does not own) and packed into two registers: a sweep then spends two
+  // bit-field extracts and two conversions per individual where code_weights spends ten instructions, ten times per
+  // SNP on the same codes.  In two steps, so that the words of the NEXT SNP's column can be requested a SNP ahead and
+  // packed when they are needed.
   auto load_words = [&](uint32_t loc_, auto &word) {
     const uint32_t *col = reinterpret_cast<const uint32_t *>(p.bed + (size_t)loc_ * p.colstride);
 #pragma unroll
     for (int t = 0; t < kItems; ++t) word[t] = col[item_or_last((uint32_t)t) / RC::kItemsPerWord];
   };
-  auto pack_codes = [&](const auto &word) -> uint32_t {
-    uint32_t out = 0u;
+  auto pack_codes = [&](const auto &word) -> uint2 {
+    uint32_t out[2] = {0u, 0u};
 #pragma unroll
     for (int t = 0; t < kItems; ++t) {
       const uint32_t i = item_or_last((uint32_t)t);
       const uint32_t c = (uint32_t)t < cnt ? (word[t] >> (RC::kCodeBits * (i % RC::kItemsPerWord))) & RC::kMask : RC::kMissing;
-      out |= c << (RC::kCodeBits * (uint32_t)t);
+      out[t / 8] |= code_nibble(c) << (4u * (uint32_t)(t % 8));
     }
-    return out;
+    return make_uint2(out[0], out[1]);
   };
-  auto load_codes = [&](uint32_t loc_) -> uint32_t {
+  auto load_codes = [&](uint32_t loc_) -> uint2 {
     uint32_t word[kItems];
     load_words(loc_, word);
     return pack_codes(word);
   };
   // the previous call's last SNP: its gamma step may be pending (column bits, exp(Elogbeta) of its last
   // pass), and its final values serve a first SNP at the same location
-  uint32_t pcodes = svalid ? load_codes(sloc) : 0x55555555u;
+  uint2 pcodes = svalid ? load_codes(sloc) : make_uint2(0u, 0u);
   if (tid < J) {
     s_sb[tid] = S->eb[tid];
     s_plam[tid] = svalid ? p.lam[(size_t)sloc * J + tid] : 0.0;
@@ -929,7 +967,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   // every later SNP's column is requested while its predecessor runs -- except at K = 16, whose 128 resident doubles
   // per thread leave no room for the words in flight (36 bytes of scratch otherwise): it loads them when the SNP starts
   constexpr bool kColAhead = KT != 16 && KT != TSAMD_NOCOL_K;
-  uint32_t codes = kColAhead ? load_codes(sched[0] & 0x7fffffffu) : 0u;
+  uint2 codes = kColAhead ? load_codes(sched[0] & 0x7fffffffu) : make_uint2(0u, 0u);
   uint32_t nword[kColAhead ? kItems : 1];
   // (default form: lam_old / eb_used live in lanes < 2K of EVERY wave and are advanced by the wave's own epilogue: lambda
   // before the pending pass' epilogue, exp(Elogbeta) of the pass that runs; eb_ran = what the last executed pass used)
@@ -969,7 +1007,10 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       uint32_t zo = 0u;  // (opaque zero: the LDS reads of exp(Elogbeta) are repeated per item instead of held in 4K registers)
       if constexpr (!BS) asm volatile("" : "+v"(zo));
       const double2 *bl = reinterpret_cast<const double2 *>(kRepl ? s_ebw[tid >> 6] : s_eb) + zo;
-      res_consume<KT, VEC, BS>(wcur, (codes >> (RC::kCodeBits * (uint32_t)t)) & RC::kMask, b0, b1, bl, acc0, acc1);
+      {
+        const uint32_t nib = nibble_of(codes, t);
+        res_consume_md<KT, BS>(wcur, (double)(nib & 3u), (double)(nib >> 2), b0, b1, bl, acc0, acc1);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef TSAMD_SCHED_TIME
@@ -1132,10 +1173,9 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
 #else
       constexpr bool kLeanStep = PARTIAL || KT > 8;
 #endif
-      auto gamma_one = [&](double (&gx)[KT], double (&wx)[KT], uint32_t code2, uint32_t &cn) {
-        double mom, dad;
-        bool ok;
-        code_weights(code2 & 3u, mom, dad, ok);
+      auto gamma_one = [&](double (&gx)[KT], double (&wx)[KT], uint32_t nib, uint32_t &cn) {
+        const double mom = (double)(nib & 3u), dad = (double)((nib >> 2) & 3u);
+        const bool ok = (nib & 15u) != 0u;  // (an observed genotype has y + (2 - y) = 2)
         double s0 = 0.0, s1 = 0.0;
         uint32_t zo = 0u;  // (opaque zero: exp(Elogbeta) is re-read from LDS where it is used, not held in 4K registers)
         asm volatile("" : "+v"(zo));
@@ -1188,7 +1228,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         __builtin_amdgcn_sched_barrier(0);
         WT wcur[KT];
         get_item(t, wcur);
-        uint32_t pcode = (pcodes >> (RC::kCodeBits * (uint32_t)t)) & RC::kMask;
+        uint32_t pcode = nibble_of(pcodes, t);
         if constexpr (VEC == 2) {
           // the item's two individuals, one after the other through ONE copy of the code (a rolled loop that
           // works on the .x halves and swaps the halves after each turn: eight items times two individuals of

@@ -75,10 +75,16 @@ def main():
         if os.environ.get("TS_OCCUPY") and rank == 0:   # "workgroups,milliseconds": a tenant takes compute units of rank 0's device
             wgs, ms = (int(x) for x in os.environ["TS_OCCUPY"].split(","))
             eng.debug_occupy(wgs, ms)
+            import time
+            time.sleep(0.3)             # (until ALL its workgroups hold their compute units, not just the first)
         if os.environ.get("TS_OCCUPY"):
             d.barrier()
         eng.run_schedule(locs[6:])      # graph replay path when long enough
-    eng.synchronize()
+    try:
+        eng.synchronize()
+    except Exception:
+        print(f"rank {rank}: synchronize failed; recoveries so far {eng.recoveries()}", flush=True)
+        raise
     if os.environ.get("TS_EXPECT_RECOVERIES"):
         assert eng.recoveries() == int(os.environ["TS_EXPECT_RECOVERIES"]), f"recoveries: {eng.recoveries()} ({eng.last_error()})"
         assert eng.launch_info()["kernels_per_snp"] == eng.cfg.max_inner

@@ -21,5 +21,5 @@ for path in sys.argv[1:]:
             busy = [x for x in v if x >= 0.5 * med]
             print(f"{name[:70]:70s} {len(v):7d} {sum(v)/1e6:10.3f} {sum(v)/len(v)/1e3:9.2f} {min(v)/1e3:9.2f} {max(v)/1e3:9.2f} "
                   f"{100*sum(v)/tot:6.2f} {len(busy):6d} {sum(busy)/len(busy)/1e3:9.2f}")
-            if "ts_schedule" in name and len(v) <= 24:  # one launch per schedule: the launches differ in length, list them
+            if any(x in name for x in ("ts_schedule", "ts_hybrid", "ts_holblock")) and len(v) <= 24:  # one launch per schedule: the launches differ in length, list them
                 print("    each launch (us): " + " ".join(f"{x/1e3:.1f}" for x in v))

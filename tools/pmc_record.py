@@ -1,7 +1,7 @@
 """Builds profiles/pass_kernel_pmc.json from the --pmc summaries that tools/profile_round3.sh wrote
-(profiles/r03_*_pmc_*.txt: per-kernel avg/min/max of each counter; FETCH_SIZE / WRITE_SIZE in KB) and the in-kernel
-timers of the diagnostic build (profiles/r03_sched_timers.txt).  bench.py reads `traffic`, the fp64 flops per update
-and the exchange time per update from it.   usage: python3 tools/pmc_record.py [dir with the r03_* files, default profiles/]"""
+(profiles/{RND}_*_pmc_*.txt: per-kernel avg/min/max of each counter; FETCH_SIZE / WRITE_SIZE in KB) and the in-kernel
+timers of the diagnostic build (profiles/{RND}_sched_timers.txt).  bench.py reads `traffic`, the fp64 flops per update
+and the exchange time per update from it.   usage: python3 tools/pmc_record.py [dir with the {RND}_* files, default profiles/]"""
 import json
 import os
 import re
@@ -9,6 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 D = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles")
+RND = sys.argv[2] if len(sys.argv) > 2 else "r04"   # file prefix of the round whose summaries are read
 LINE = re.compile(r"^(.*?)\s+([A-Z][A-Z0-9_]+)\s+n=\s*(\d+)\s+avg=\s*([\d.]+)\s+min=\s*([\d.]+)\s+max=\s*([\d.]+)")
 UPD = 200  # tools/profile_round3.sh: the largest launch of the counter runs is the 200-update schedule
 
@@ -40,7 +41,7 @@ def kb(fetch, write):
 
 def timers(tag):
     """exchange / gamma / sweep microseconds per SNP from the diagnostic build's line for `tag` (e.g. 'N=1000000 K=8')"""
-    path = os.path.join(D, "r03_sched_timers.txt")
+    path = os.path.join(D, f"{RND}_sched_timers.txt")
     if not os.path.exists(path):
         return None
     for ln in open(path):
@@ -57,7 +58,7 @@ def timers(tag):
 
 
 def schedule_record(prefix, n, k, kernel_needle):
-    f, w, c = maxima(f"r03_{prefix}_pmc_fetch_size.txt"), maxima(f"r03_{prefix}_pmc_write_size.txt"), maxima(f"r03_{prefix}_pmc_f64.txt")
+    f, w, c = maxima(f"{RND}_{prefix}_pmc_fetch_size.txt"), maxima(f"{RND}_{prefix}_pmc_write_size.txt"), maxima(f"{RND}_{prefix}_pmc_f64.txt")
     fs, ws = pick(f, "FETCH_SIZE", kernel_needle), pick(w, "WRITE_SIZE", kernel_needle)
     if fs is None or ws is None:
         return None
@@ -65,7 +66,7 @@ def schedule_record(prefix, n, k, kernel_needle):
         "mode": "schedule", "kernel": kernel_needle.strip("<") + ">", "n": n, "k": k, "n_gpus": 1, "updates_in_launch": UPD,
         "FETCH_SIZE_KB_max": fs, "WRITE_SIZE_KB_max": ws,
         "hbm_bytes_per_launch": kb(fs, ws), "hbm_bytes_per_update": kb(fs, ws) / UPD,
-        "source_files": [f"profiles/r03_{prefix}_pmc_fetch_size.txt", f"profiles/r03_{prefix}_pmc_write_size.txt"],
+        "source_files": [f"profiles/{RND}_{prefix}_pmc_fetch_size.txt", f"profiles/{RND}_{prefix}_pmc_write_size.txt"],
     }
     fma, mul, add, trn = (pick(c, "SQ_INSTS_VALU_" + x + "_F64", kernel_needle) for x in ("FMA", "MUL", "ADD", "TRANS"))
     if None not in (fma, mul, add, trn):
@@ -77,30 +78,31 @@ def schedule_record(prefix, n, k, kernel_needle):
             "SQ_INSTS_VALU_TRANS_F64_max": trn,
             "fp64_flops_per_update": (2.0 * fma + mul + add + trn) * scale,
             "fp64_instructions_per_wave_and_update": (fma + mul + add + trn) / UPD / 32.0,  # (an entry covers the 32 waves of 8 CUs)
-            "flops_source_files": [f"profiles/r03_{prefix}_pmc_f64.txt"],
+            "flops_source_files": [f"profiles/{RND}_{prefix}_pmc_f64.txt"],
             "flops_note": ("(2 FMA + MUL + ADD + TRANS) wave instructions x 64 lanes, summed over the 32 shader-engine entries of the "
                            "200-update launch, / 200; lanes of partially filled waves and the transcendental estimates count as "
                            "one flop per lane"),
         })
-    tm = timers(f"N={n} K={k}")
+    tm = None if "ts_hybrid" in kernel_needle else timers(f"N={n} K={k}")
     if tm:
         rec.update({"exchange_us_per_update": tm["exchange_us"], "exchanges_per_update": tm["exchanges"],
                     "gamma_us_per_update": tm["gamma_us"], "sweep_us_per_update": tm["sweep_us"],
                     "epilogue_us_per_update": tm["epilogue_us"],
                     "exchange_source": ("in-kernel timers of the diagnostic build (-DTSAMD_SCHED_TIME, workgroup 0, 2 000-SNP launch; "
-                                        "the timers themselves cost about 2 us per SNP): profiles/r03_sched_timers.txt")})
+                                        f"the timers themselves cost about 2 us per SNP): profiles/{RND}_sched_timers.txt")})
     return rec
 
 
 records = []
 for prefix, n, k, needle in (("k8", 1_000_000, 8, "ts_schedule<8"), ("k16_n500k", 500_000, 16, "ts_schedule<16"),
-                             ("k20_n125k", 125_000, 20, "ts_schedule<20")):
+                             ("k20_n125k", 125_000, 20, "ts_schedule<20"),
+                             ("k20_n1m", 1_000_000, 20, "ts_hybrid<20")):   # (round 4: config 5 on one GPU runs ts_hybrid)
     r = schedule_record(prefix, n, k, needle)
     if r:
         records.append(r)
 
 N = 1_000_000
-f, w = maxima("r03_k8_per_snp_pmc_fetch_size.txt"), maxima("r03_k8_per_snp_pmc_write_size.txt")
+f, w = maxima(f"{RND}_k8_per_snp_pmc_fetch_size.txt"), maxima(f"{RND}_k8_per_snp_pmc_write_size.txt")
 if pick(f, "FETCH_SIZE", "ts_resident<8>") is not None:
     records.append({
         "mode": "snp", "kernel": "ts_resident<8> / ts_pass<8,true,256,1>", "n": N, "k": 8, "n_gpus": 1,
@@ -111,9 +113,9 @@ if pick(f, "FETCH_SIZE", "ts_resident<8>") is not None:
         "first_pass_hbm_bytes_per_launch": kb(pick(f, "FETCH_SIZE", "ts_pass<8, true"), pick(w, "WRITE_SIZE", "ts_pass<8, true")),
         "algorithmic_bytes_per_launch": 64_250_000, "first_pass_algorithmic_bytes_per_launch": 264_500_000,
         "note": "TSAMD_PERSISTENT=0: the resident kernel reads the weights once per SNP (64 MB) for its 9 passes",
-        "source_files": ["profiles/r03_k8_per_snp_pmc_fetch_size.txt", "profiles/r03_k8_per_snp_pmc_write_size.txt"],
+        "source_files": [f"profiles/{RND}_k8_per_snp_pmc_fetch_size.txt", f"profiles/{RND}_k8_per_snp_pmc_write_size.txt"],
     })
-f, w = maxima("r03_k20_n1m_pmc_fetch_size.txt"), maxima("r03_k20_n1m_pmc_write_size.txt")
+f, w = maxima(f"{RND}_k20_n1m_pmc_fetch_size.txt"), maxima(f"{RND}_k20_n1m_pmc_write_size.txt")
 if pick(f, "FETCH_SIZE", "ts_pass<20, false") is not None:
     records.append({
         "mode": "pass", "kernel": "ts_pass<20,false,256,2> / ts_pass<20,true,256,1>", "n": N, "k": 20, "n_gpus": 1,
@@ -123,7 +125,7 @@ if pick(f, "FETCH_SIZE", "ts_pass<20, false") is not None:
         "hbm_bytes_per_launch": kb(pick(f, "FETCH_SIZE", "ts_pass<20, false"), pick(w, "WRITE_SIZE", "ts_pass<20, false")),
         "first_pass_hbm_bytes_per_launch": kb(pick(f, "FETCH_SIZE", "ts_pass<20, true"), pick(w, "WRITE_SIZE", "ts_pass<20, true")),
         "algorithmic_bytes_per_launch": 160_250_000, "first_pass_algorithmic_bytes_per_launch": 648_500_000,
-        "source_files": ["profiles/r03_k20_n1m_pmc_fetch_size.txt", "profiles/r03_k20_n1m_pmc_write_size.txt"],
+        "source_files": [f"profiles/{RND}_k20_n1m_pmc_fetch_size.txt", f"profiles/{RND}_k20_n1m_pmc_write_size.txt"],
     })
 sys.path.insert(0, ROOT)
 from terastructure_amd.build import kernel_sources_sha  # noqa: E402
