@@ -108,6 +108,13 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
   if (!res_exchange<KT, WR>(xb, p, xseq0 + 1u, 1u, 0.0, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(xseq0 + 1u, true, par, serial),
                             WR == 0 ? (unsigned long long)p.probe_ticks : kResWaitTicks))
     return;
+  if constexpr (WR > 0) {
+    // (sharded: the commit exchange of ts_schedule -- the entry exchange's verdict is not collective by itself)
+    xcount += 1u;
+    if (!res_exchange<KT, WR>(xb, p, xseq0 + xcount, 1u, 0.0, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(xseq0 + xcount, true, par, serial),
+                              kResWaitTicks / 3ull))
+      return;
+  }
   // the weights of the register and LDS items: loaded once, kept for the whole launch
   double buf[R][KT];
 #pragma unroll

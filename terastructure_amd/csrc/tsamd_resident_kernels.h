@@ -853,6 +853,17 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   if (!res_exchange<KT, WR>(xb, p, xseq0 + 1u, 1u, 0.0, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(xseq0 + 1u, true, par, serial),
                             WR == 0 ? (unsigned long long)p.probe_ticks : kResWaitTicks))
     return;
+  if constexpr (WR > 0) {
+    // Sharded: the entry exchange's verdict is not collective -- a rank whose last workgroup gave up a moment before the
+    // others' rows arrived fails while its peers, which had its leaders' sums already, pass.  A second empty exchange
+    // commits it: a rank that failed the first never posts here, so nobody completes it and EVERY rank gives up with its
+    // state intact (and replays, csrc/tsamd.hip).  Bounded by a third of the entry's wait: every rank that passed the
+    // first exchange posts within microseconds, and the ranks' replays must start within one peer-to-peer wait of each other.
+    xcount += 1u;
+    if (!res_exchange<KT, WR>(xb, p, xseq0 + xcount, 1u, 0.0, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(xseq0 + xcount, true, par, serial),
+                              kResWaitTicks / 3ull))
+      return;
+  }
   // the shard's weights: loaded once (two items in flight at a time), kept for the whole launch
   WT buf[kItems][KT];
 #pragma unroll

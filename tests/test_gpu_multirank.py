@@ -55,7 +55,8 @@ def _run_ranks(tmp_path, mode, world, n, l, k, seed, nsnp, extra_env=None, ok_co
             raise
         outs.append(out)
     for rank, (p, out) in enumerate(zip(procs, outs)):
-        assert p.returncode in ok_codes, f"rank {rank} failed:\n{out[-3000:]}"
+        assert p.returncode in ok_codes, f"rank {rank} failed:\n{out[-3000:]}\n" + "".join(
+            f"---- rank {r} (exit code {q.returncode}) ----\n{o[-1500:]}\n" for r, (q, o) in enumerate(zip(procs, outs)) if r != rank)
     if any(p.returncode != 0 for p in procs):
         return outs
     return [np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in range(world)]
@@ -186,7 +187,7 @@ def test_sharded_ranks_switch_launch_modes_mid_run(tmp_path, world):
     _assert_ranks_match(res, orc, its)
 
 
-@pytest.mark.parametrize("world,n,k", [(2, 40_000, 8), (3, 30_000, 20)])
+@pytest.mark.parametrize("world,n,k", [(2, 40_000, 8), (3, 30_000, 20), (2, 30_000, 20), (2, 60_000, 12)])
 def test_sharded_schedule_that_cannot_be_resident_is_replayed_on_every_rank(tmp_path, world, n, k):
     """A tenant holds compute units when the ranks' ts_schedule launches start: the entry exchange (which spans the ranks)
     times out on every rank with every rank's state intact; every rank lowers itself to one launch per pass and replays the
