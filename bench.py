@@ -497,14 +497,19 @@ def main():
           # to for this measurement only)
           per_snp = None
           if mode == "schedule":
-              # (a sharded context has no launch-per-SNP mode: its other sequence is one launch per pass)
+              # (a sharded context has no launch-per-SNP mode, and neither has a shard above the register capacity -- ts_hybrid:
+              # their other sequence is one launch per pass)
               sub = ts.LAUNCH_PER_SNP if world == 1 else ts.LAUNCH_PER_PASS
-              eng.set_launch_mode(sub)
+              try:
+                  eng.set_launch_mode(sub)
+              except ts.TsamdError:
+                  sub = ts.LAUNCH_PER_PASS
+                  eng.set_launch_mode(sub)
               try:
                   pr, _ = profiled(min(args.steps, 300))
               finally:
                   eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
-              sub_mode = "snp" if (world == 1 and eng.cfg.max_inner > 2) else "pass"
+              sub_mode = "snp" if (sub == ts.LAUNCH_PER_SNP and eng.cfg.max_inner > 2) else "pass"
           else:
               pr, _ = profiled(min(args.steps, 300))
               sub_mode = mode

@@ -176,6 +176,24 @@ def test_sharded_schedule_kernel_three_levels(tmp_path, world, n, k, thresh):
         assert np.array_equal(res[0]["lam"], ref[0]["lam"]) and np.array_equal(res[0]["gamma"], ref[0]["gamma"])
 
 
+@pytest.mark.parametrize("world,n,k,thresh", [(2, 400_000, 20, None), (2, 600_000, 20, 15.0), (3, 1_200_000, 8, None)])
+def test_sharded_hybrid_kernel_matches_oracle(tmp_path, world, n, k, thresh):
+    """Shards above ts_schedule's register capacity (with the ranks sharing one GPU each gets CUs / world workgroups: 128 x 256 x 5
+    individuals at K = 20 for two ranks): every rank runs ts_hybrid<K, WR> -- weights in registers + LDS, the rest streamed
+    (600 000 at K = 20: two of a thread's ten individuals; 1 200 000 at K = 8 on three ranks: none, LDS items only) -- with the
+    in-launch exchange spanning the ranks.  BASELINE config 5's 2-GPU point (500 000 per rank) takes this route on a node."""
+    l, seed, nsnp = 24, 79, 24
+    env, over = {"TS_EXPECT_KPS": "0", "TS_EXPECT_HYBRID": "1"}, {}
+    if thresh is not None:
+        env["TS_CONV_THRESH"] = str(thresh)
+        over["meanchangethresh"] = thresh
+    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp, extra_env=env)
+    orc, its = _oracle_run(n, l, k, seed, nsnp, **over)
+    if thresh is not None:
+        assert len(set(its)) >= 2, f"pass counts do not vary: {sorted(set(its))}"
+    _assert_ranks_match(res, orc, its)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_ranks_switch_launch_modes_mid_run(tmp_path, world):
     """ts_schedule (in-launch exchange across the ranks) -> one launch per pass (epoch-tagged peer-to-peer rows with the
