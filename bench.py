@@ -656,24 +656,28 @@ def main():
                   upd_ = roofline["updates_per_launch"]
                   launch_s_ = roofline["avg_launch_us"] * 1e-6
                   moved_h = ppu_ * streamed * 8.0 * k + sc * (16.0 * k + 8.0) + streamed * 16.0 * k + (ppu_ + 1.0) * sc / 4.0
-                  fp64 = {key: roofline[key] for key in ("achieved", "peak", "unit", "frac", "flops_per_update", "flops_per_update_hand_count",
-                                                         "flops_source")}
-                  fp64["bound"] = "fp64_valu"
-                  roofline.update({
-                      "bound": "hbm",
-                      "kernel": (f"ts_hybrid<{k}> (one launch = {upd_:.0f} SNP updates; of a thread's {geo['indivs_per_thread']} individuals "
-                                 f"{geo['on_chip_per_thread']} keep their weights in registers + LDS for the whole launch, the weights of the "
-                                 "others are re-read every pass; gamma and c_n of all stream through the gamma step)"),
-                      "achieved": round(moved_h * upd_ / launch_s_ / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(moved_h * upd_ / launch_s_ / 1e9 / HBM_PEAK_GBS, 4),
-                      "algorithmic_bytes_per_update": moved_h,
-                      "algorithmic_bytes_note": ("passes x streamed individuals x 8K (weights re-read) + N (16K + 8) (gamma, c_n read and written) + "
-                                                 "streamed x 16K (their weights read and written by the gamma step) + (passes + 1) N / 4 (columns)"),
-                      "streamed_individuals": int(streamed), "on_chip_individuals": int(on_chip),
-                      "fp64_valu": fp64,
-                      "bound_note": ("memory: the streamed weights (Infinity Cache / HBM) and the gamma step's streams; the exchanges and epilogues "
-                                     "(`latency`) run with the memory system idle"),
-                  })
+                  kernel_h = (f"ts_hybrid<{k}> (one launch = {upd_:.0f} SNP updates; of a thread's {geo['indivs_per_thread']} individuals "
+                              f"{geo['on_chip_per_thread']} keep their weights in registers + LDS for the whole launch, the weights of the "
+                              "others are re-read every pass; gamma and c_n of all stream through the gamma step)")
+                  hbm_h = {"bound": "hbm", "achieved": round(moved_h * upd_ / launch_s_ / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(moved_h * upd_ / launch_s_ / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_update": moved_h,
+                           "algorithmic_bytes_note": ("passes x streamed individuals x 8K (weights re-read) + N (16K + 8) (gamma, c_n read and "
+                                                      "written) + streamed x 16K (their weights read and written by the gamma step) + "
+                                                      "(passes + 1) N / 4 (columns)"),
+                           "streamed_individuals": int(streamed), "on_chip_individuals": int(on_chip)}
+                  if streamed > 0:   # memory binds: the streamed weights and the gamma step's streams
+                      fp64 = {key: roofline[key] for key in ("achieved", "peak", "unit", "frac", "flops_per_update", "flops_per_update_hand_count",
+                                                             "flops_source")}
+                      fp64["bound"] = "fp64_valu"
+                      roofline.update(hbm_h)
+                      roofline.update({
+                          "kernel": kernel_h, "fp64_valu": fp64,
+                          "bound_note": ("memory: the streamed weights (Infinity Cache / HBM) and the gamma step's streams; the exchanges and "
+                                         "epilogues (`latency`) run with the memory system idle"),
+                      })
+                  else:              # everything on chip: like ts_schedule, with all of gamma streamed through the gamma step
+                      roofline["kernel"] = kernel_h
+                      roofline["hbm"] = hbm_h
                   roofline["traffic"] = None if not rec.get("hbm_bytes_per_update") else rec["hbm_bytes_per_update"] * upd_
           else:
               roofline = per_snp
