@@ -250,6 +250,10 @@ int tsamd_probe_stream(tsamd_ctx *ctx, uint32_t reps, double *read_us, double *r
  * k <= 32 and a shard that fits the register file of the GPU's compute units: 256 workgroups x
  *   k <= 8: 4096,  k = 9..16: 256 floor(128/k),  k = 17..24: 256 floor(112/k),  k = 25..32: 768   individuals
  * (1 048 576 per GPU at k <= 8, 524 288 at k = 16, 327 680 at k = 20); the whole-schedule kernel also nodekappa == 0.5.
+ * A LARGER shard (k <= 32, nodekappa == 0.5, one GPU or up to 4 ranks connected peer to peer) still runs a whole schedule
+ * as ONE launch (kernels_per_snp == 0): ts_hybrid keeps the weights of the first individuals of every thread in registers
+ * and LDS and re-reads the others every pass (tsamd_schedule_geometry: on_chip_per_thread < indivs_per_thread); it has no
+ * one-launch-per-SNP form (TSAMD_LAUNCH_PER_SNP is refused).  TSAMD_HYBRID=0 restores one launch per pass for such shards.
  * TSAMD_RESIDENT=0 / TSAMD_PERSISTENT=0 in the environment disable them. */
 int tsamd_launch_info(tsamd_ctx *ctx, uint32_t *kernels_per_snp, uint32_t *plain_grid, uint32_t *first_grid);
 /* Launch geometry of the context's resident kernel of `mode` (TSAMD_LAUNCH_PER_SNP: ts_resident, TSAMD_LAUNCH_PER_SCHEDULE:
