@@ -548,6 +548,8 @@ void choose_sharded_schedule(tsamd_ctx *c) {
   c->sched_chunk = my_chunk;
   c->hybrid = hybrid;
   c->persistent = c->can_persistent = true;
+  // (validation-mode schedules run batched on every rank alike: ts_holblock<K, WR>, level 2 of its wide exchange in Xchg::res_wide)
+  c->can_holblock = !hybrid && kHolblockBlocksPerCu[cfg.k]() >= 1;
 }
 
 // Switch the kernel sequence to the exchange buffer (rows + epoch flags pushed by every

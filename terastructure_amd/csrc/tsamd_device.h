@@ -90,6 +90,9 @@ struct Xchg {
   // system-scope stores over xGMI); every workgroup then polls its own rank's copy -- local memory -- for world * 8 rows.
   // Laid out by ResLay<K>::rank_sums: [2 slots][2 regions][kMaxRanks * 8 rows][granules per row of the context's K <= 128]
   unsigned long long res_sums[2 * 2 * kMaxRanks * 8 * 128];
+  // ... and the same for ts_holblock's wide rows (a batch of validation locations per exchange: up to 512 granules per row,
+  // one region): [2 slots][kMaxRanks * 8 rows][512 granules] (WideLay::rank_sums)
+  unsigned long long res_wide[2 * kMaxRanks * 8 * 512];
 };
 
 struct ResXchg;  // in-launch exchange buffer of the resident kernels (tsamd_resident_kernels.h)

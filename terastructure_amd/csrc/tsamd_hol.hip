@@ -16,12 +16,22 @@ static_assert(TSAMD_K <= kResidentMaxK, "ts_holblock holds the shard's weights i
 // geometry as ts_schedule (its per-thread partial sums are the same sums)
 void TSAMD_CAT(launch_holblock_k, TSAMD_K)(uint32_t grid, uint32_t chunk, hipStream_t stream, const DevParams &p, uint32_t par,
                                            const uint32_t *sched, uint32_t n, uint32_t serial) {
-  hipLaunchKernelGGL((ts_holblock<TSAMD_K>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.w, p.npad, chunk, par, sched, n, p.res, serial, p);
+  // (a sharded context: the instantiation whose level 2 spans up to 8 ranks' group leaders -- 32 row pairs per lane)
+  if (p.xchg_world == 0u)
+    hipLaunchKernelGGL((ts_holblock<TSAMD_K, 0>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.w, p.npad, chunk, par, sched, n, p.res, serial, p);
+  else if (p.xchg_world <= 2u)
+    hipLaunchKernelGGL((ts_holblock<TSAMD_K, 8>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.w, p.npad, chunk, par, sched, n, p.res, serial, p);
+  else
+    hipLaunchKernelGGL((ts_holblock<TSAMD_K, 32>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.w, p.npad, chunk, par, sched, n, p.res, serial,
+                       p);
 }
 
 int TSAMD_CAT(holblock_blocks_per_cu_k, TSAMD_K)() {
-  int nb = 0;
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ts_holblock<TSAMD_K>, kResidentBlock, 0) == hipSuccess ? nb : 0;
+  int nb = 0, nb2 = 0, nb3 = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ts_holblock<TSAMD_K, 0>, kResidentBlock, 0) != hipSuccess) nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, ts_holblock<TSAMD_K, 8>, kResidentBlock, 0) != hipSuccess) nb2 = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, ts_holblock<TSAMD_K, 32>, kResidentBlock, 0) != hipSuccess) nb3 = 0;
+  return nb < nb2 ? (nb < nb3 ? nb : nb3) : (nb2 < nb3 ? nb2 : nb3);
 }
 
 // locations per exchange / per launch (what the host cuts a validation-mode schedule into)

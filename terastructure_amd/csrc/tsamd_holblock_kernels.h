@@ -1,4 +1,4 @@
-// ts_holblock<K>: a run of VALIDATION-mode SNP updates in one launch, BX locations at a time (gfx950).
+// ts_holblock<K, WR>: a run of VALIDATION-mode SNP updates in one launch, BX locations at a time (gfx950).
 //
 // The reference's validation block (compute_likelihood, src/snpsamplinge.cc:476-498; snp_likelihood,
 // src/snpsamplinge.hh:322-361) calls optimize_lambda(loc) once per validation location with _hol_mode set: the workers
@@ -16,6 +16,7 @@
 // same halving butterfly per location (res_fold<K>), the four waves in order, the same member / group order in the
 // exchange -- so lambda, exp(Elogbeta), pass counts and the State left behind equal ts_schedule's for the same
 // entries BIT FOR BIT (tests/test_gpu_holblock.py).
+// WR > 0: one launch per rank of a sharded run, level 2 of the exchanges across the ranks (wide rows in Xchg::res_wide).
 // The host (csrc/tsamd.hip) launches it for hol-mode schedules of pairwise distinct locations on a context that runs
 // ts_schedule, after the first entry of the block has gone through ts_schedule (which applies the pending gamma step
 // of the last training SNP, src/snpsamplinge.cc:664-667); no gamma step is ever pending when this kernel starts.
@@ -37,7 +38,7 @@ constexpr int hol_batch(int k) {
 }
 constexpr uint32_t kHolChunk = 1u << 14;
 
-template <int KT>
+template <int KT, int WR>
 __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
                                                       const uint32_t *sched, uint32_t n_sched, ResXchg *xb, uint32_t serial, const DevParams p) {
   constexpr int BLOCK = 256, kWaves = BLOCK / 64, kItems = resident_items(KT);
@@ -102,10 +103,17 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
   if (tid < 4) s_alive[tid] = 1;
   __syncthreads();
   uint32_t xcount = 1u;
-  // the entry exchange: empty rows, nothing modified yet.  All workgroups resident?  (ts_schedule's, in its layout)
-  if (!res_exchange<KT, 0>(xb, p, xseq0 + 1u, 1u, 0.0, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(xseq0 + 1u, true, par, serial),
-                           (unsigned long long)p.probe_ticks))
+  // the entry exchange: empty rows, nothing modified yet.  All workgroups resident?  (ts_schedule's, in its layout; sharded --
+  // WR > 0, the exchange spans the ranks -- committed by a second one, as in ts_schedule)
+  if (!res_exchange<KT, WR>(xb, p, xseq0 + 1u, 1u, 0.0, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(xseq0 + 1u, true, par, serial),
+                            WR == 0 ? (unsigned long long)p.probe_ticks : kResWaitTicks))
     return;
+  if constexpr (WR > 0) {
+    xcount += 1u;
+    if (!res_exchange<KT, WR>(xb, p, xseq0 + xcount, 1u, 0.0, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(xseq0 + xcount, true, par, serial),
+                              kResWaitTicks / 3ull))
+      return;
+  }
   // the shard's weights: loaded once, never modified (theta is frozen in validation mode), never written back
   double buf[kItems][KT];
 #pragma unroll
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
       }
       xcount += 1u;
       const uint32_t tag = xseq0 + xcount;
-      if (!res_exchange<KX, 0, kResOneLevelGrid, Wide>(xb, p, tag, 1u, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial),
+      if (!res_exchange<KX, WR, kResOneLevelGrid, Wide>(xb, p, tag, 1u, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial),
                                                        kResWaitTicks))
         return;
       TSAMD_BK(tk_xchg);

@@ -91,7 +91,7 @@ struct ResLay {
   }
 };
 
-// the same row / sum / flat positions for rows of 2 KX values in ResXchg::wide (one region; one GPU)
+// the same row / sum / flat positions for rows of 2 KX values in ResXchg::wide (one region)
 template <int KX>
 struct WideLay {
   static constexpr uint32_t GR = 32u * (uint32_t)res_blocks(KX);
@@ -105,8 +105,13 @@ struct WideLay {
   static __device__ __forceinline__ unsigned long long *flat(ResXchg *xb, uint32_t, uint32_t slot, uint32_t row) {
     return xb->wide + (slot * (uint32_t)kResOneLevelGrid + row) * GR;
   }
-  static __device__ __forceinline__ unsigned long long *rank_sums(Xchg *x, uint32_t, uint32_t, uint32_t) { return x->res_sums; }  // (never used: one GPU)
+  // sharded: level 2 in Xchg::res_wide of every rank, row r * 8 + g of the slot
+  static __device__ __forceinline__ unsigned long long *rank_sums(Xchg *x, uint32_t, uint32_t slot, uint32_t row) {
+    return x->res_wide + (slot * (uint32_t)(kMaxRanks * kResGroups) + row) * GR;
+  }
 };
+static_assert(sizeof(((Xchg *)nullptr)->res_wide) / sizeof(unsigned long long) == 2u * kMaxRanks * kResGroups * (unsigned)kResWideGran,
+              "Xchg::res_wide holds two slots of world x 8 wide rows");
 
 constexpr unsigned long long kResWaitTicks = 300000000ull;  // 3 s at 100 MHz
 // what a failing wait leaves in the pinned host word [0] (DevParams::host_error): the tag, whether the launch had

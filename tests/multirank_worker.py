@@ -89,6 +89,14 @@ def main():
     except Exception:
         print(f"rank {rank}: synchronize failed; recoveries so far {eng.recoveries()}", flush=True)
         raise
+    if os.environ.get("TS_HOL_LOCS"):         # a validation block (distinct locations, hol mode), then training again
+        nhol = int(os.environ["TS_HOL_LOCS"])
+        eng.run_schedule(np.arange(nhol, dtype=np.uint32), 1)
+        eng.run_schedule(locs[:4])
+        eng.synchronize()
+        info = eng.holblock_info()
+        want = int(os.environ.get("TS_EXPECT_HOLBLOCKS", "-1"))
+        assert want < 0 or info["launches"] == want, info
     if os.environ.get("TS_EXPECT_RECOVERIES"):
         assert eng.recoveries() == int(os.environ["TS_EXPECT_RECOVERIES"]), f"recoveries: {eng.recoveries()} ({eng.last_error()})"
         assert eng.launch_info()["kernels_per_snp"] == eng.cfg.max_inner

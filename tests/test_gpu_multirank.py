@@ -194,6 +194,34 @@ def test_sharded_hybrid_kernel_matches_oracle(tmp_path, world, n, k, thresh):
     _assert_ranks_match(res, orc, its)
 
 
+@pytest.mark.parametrize("world,n,k,thresh", [(2, 40_000, 8, None), (2, 60_000, 20, 30.0), (4, 90_000, 16, None), (3, 50_000, 5, 6.0)])
+def test_sharded_validation_block_is_batched_and_matches(tmp_path, world, n, k, thresh):
+    """A validation-mode schedule on a sharded context that runs ts_schedule: every rank runs it as ts_holblock<K, WR> launches
+    (wide rows exchanged across the ranks through Xchg::res_wide).  Against the oracle, and bit for bit against the same run
+    with TSAMD_HOLBLOCK=0 (entry by entry inside ts_schedule)."""
+    l, seed, nsnp, nhol = 24, 81, 20, 21
+    env, over = {"TS_EXPECT_KPS": "0", "TS_HOL_LOCS": str(nhol), "TS_EXPECT_HOLBLOCKS": "1"}, {}
+    if thresh is not None:
+        env["TS_CONV_THRESH"] = str(thresh)
+        over["meanchangethresh"] = thresh
+    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp, extra_env=env)
+    orc, its = _oracle_run(n, l, k, seed, nsnp, **over)
+    locs = np.random.default_rng(seed + 3).integers(0, l, size=nsnp)
+    its_hol = [orc.snp_update(int(x), 1) for x in range(nhol)]
+    its2 = its + its_hol + [orc.snp_update(int(x)) for x in locs[:4]]
+    if thresh is not None:
+        assert len(set(its_hol)) >= 2, its_hol
+    for r in res:
+        assert rel_err(r["lam"], orc.lambda_()) < 1e-9 and rel_err(r["gamma"], orc.gamma()) < 1e-9
+        assert np.array_equal(r["cnt"][:, 0], orc.c_indiv()) and int(r["passes"]) == sum(its2)
+    for r in res[1:]:
+        assert np.array_equal(r["lam"], res[0]["lam"])
+    (tmp_path / "single").mkdir()
+    ref = _run_ranks(tmp_path / "single", "p2p", world, n, l, k, seed, nsnp,
+                     extra_env=dict(env, TSAMD_HOLBLOCK="0", TS_EXPECT_HOLBLOCKS="0"))
+    assert np.array_equal(res[0]["lam"], ref[0]["lam"]) and np.array_equal(res[0]["gamma"], ref[0]["gamma"])
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_ranks_switch_launch_modes_mid_run(tmp_path, world):
     """ts_schedule (in-launch exchange across the ranks) -> one launch per pass (epoch-tagged peer-to-peer rows with the
