@@ -276,8 +276,10 @@ int tsamd_schedule_geometry(tsamd_ctx *ctx, int mode, uint32_t *workgroups, uint
  * sub-batch, ONE in-launch exchange per pass for the whole batch, the K x 2 epilogues side by side, per-location
  * convergence) -- after the call's first entry, which goes the ordinary way because it applies the pending gamma step of
  * the last training update.  Results equal the entry-by-entry path bit for bit (every per-location sum keeps its order).
- * Repeated locations cut the call into blocks of distinct ones.  batch = 0: the context runs such calls entry by entry
- * (other launch modes, sharded contexts, TSAMD_HOLBLOCK=0).  launches / locations: ts_holblock launches so far and the
+ * Repeated locations cut the call into blocks of distinct ones.  A sharded context (tsamd_p2p_connect) that runs
+ * TSAMD_LAUNCH_PER_SCHEDULE with ts_schedule does the same on every rank alike (the batch's rows are exchanged across the
+ * ranks).  batch = 0: the context runs such calls entry by entry (other launch modes, shards above the register capacity,
+ * TSAMD_HOLBLOCK=0 -- read per call; the same on every rank of a sharded run).  launches / locations: ts_holblock launches so far and the
  * entries they covered.  Replaces the loop of compute_likelihood, src/snpsamplinge.cc:476-498. */
 int tsamd_holblock_info(tsamd_ctx *ctx, uint32_t *batch, uint64_t *launches, uint64_t *locations);
 /* Selects how the context launches from now on: one kernel per pass, one resident kernel for the plain passes of
