@@ -14,7 +14,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.spawns]
 
 def test_bench_json_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "20",
-                        "--individuals", "30000", "--snps", "300", "--pops", "8", "--cpu-seconds", "1"],
+                        "--individuals", "30000", "--snps", "1000", "--pops", "8", "--cpu-seconds", "1"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -61,6 +61,11 @@ def test_bench_json_contract():
     assert set(om) == {"launch_per_snp", "launch_per_pass"} and all(o["ok"] and o["c_n_equal"] for o in om.values())
     assert pv["kernels_per_snp"] == 0 and om["launch_per_snp"]["kernels_per_snp"] == 2 and om["launch_per_pass"]["kernels_per_snp"] == 10
     assert sum(d["inner_passes_histogram"].values()) == 60
+    assert isinstance(rf["counter_records"], str) and rf["counter_records"]      # fresh, absent for this shape, or stale (then: hand count)
+    vb = d["validation_block"]                                                # floor(0.005 L) = 5 locations x N / 100 held-out individuals
+    assert vb["locations"] == 5 and vb["heldout_per_location"] == 300 and vb["kernel"].startswith("ts_holblock<8>: 16 locations")
+    assert vb["seconds_per_report"] > 0 and vb["entry_by_entry_seconds_per_report"] > 0 and vb["evaluation_only_seconds"] > 0
+    assert 0 < vb["heldout_entries"] <= 5 * 300 and vb["mean_loglik"] < 0
 
 
 def test_bench_short_run_matches_long_run():
