@@ -64,7 +64,7 @@ def test_bench_json_contract():
     assert isinstance(rf["counter_records"], str) and rf["counter_records"]      # fresh, absent for this shape, or stale (then: hand count)
     vb = d["validation_block"]                                                # floor(0.005 L) = 5 locations x N / 100 held-out individuals
     assert vb["locations"] == 5 and vb["heldout_per_location"] == 300 and vb["kernel"].startswith("ts_holblock<8>: 16 locations")
-    assert vb["seconds_per_report"] > 0 and vb["entry_by_entry_seconds_per_report"] > 0 and vb["evaluation_only_seconds"] > 0
+    assert vb["seconds_per_report"] > 0 and vb["entry_by_entry_seconds_per_report"] > 0 and vb["evaluation_only_seconds"] >= 0
     assert 0 < vb["heldout_entries"] <= 5 * 300 and vb["mean_loglik"] < 0
 
 
