@@ -491,11 +491,14 @@ bool resident_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, 
 // rounds each; the first hy_reg_items(K) + hy_lds_items(K) rounds of a workgroup stay on chip, the rest is streamed.
 bool hybrid_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, uint32_t *chunk) {
   if (cap == 0u || (int)k > kResidentMaxK) return false;
-  const uint32_t ch = (npad + cap - 1u) / cap;
+  // (the kernel is bound by memory: ALL `cap` workgroups take an equal share -- a multiple of 16 individuals, i.e. of a column
+  // word and of 128 bytes of a weight row -- rather than whole 256-thread rounds on fewer workgroups; a workgroup's last round
+  // is then partly filled)
+  const uint32_t ch = ((npad + cap - 1u) / cap + 15u) / 16u * 16u;
   const uint32_t r = (ch + (uint32_t)kResidentBlock - 1u) / (uint32_t)kResidentBlock;
   if (r > (uint32_t)(hy_reg_items((int)k) + hy_lds_items((int)k) + kHybridMaxStreamed)) return false;
-  *chunk = r * (uint32_t)kResidentBlock;
-  *grid = (npad + *chunk - 1u) / *chunk;
+  *chunk = ch;
+  *grid = (npad + ch - 1u) / ch;
   return true;
 }
 
@@ -1983,10 +1986,10 @@ int tsamd_schedule_geometry(tsamd_ctx *c, int mode, uint32_t *workgroups, uint32
   const uint32_t grid = sched ? c->sched_grid : c->res_grid, chunk = sched ? c->sched_chunk : c->res_chunk;
   const uint32_t one = sched ? (uint32_t)kResOneLevelGrid : (c->cfg.k <= 8u ? 16u : 0u);
   if (workgroups) *workgroups = grid;
-  if (indivs_per_thread) *indivs_per_thread = chunk / (uint32_t)kResidentBlock * (uint32_t)resident_vec((int)c->cfg.k);
+  if (indivs_per_thread) *indivs_per_thread = (chunk + (uint32_t)kResidentBlock - 1u) / (uint32_t)kResidentBlock * (uint32_t)resident_vec((int)c->cfg.k);
   if (exchange_levels) *exchange_levels = (grid == 1u && c->cfg.world == 1u) ? 0u : (c->cfg.world == 1u && grid <= one) ? 1u : 2u;
   if (on_chip_per_thread) {
-    const uint32_t per = chunk / (uint32_t)kResidentBlock * (uint32_t)resident_vec((int)c->cfg.k);
+    const uint32_t per = (chunk + (uint32_t)kResidentBlock - 1u) / (uint32_t)kResidentBlock * (uint32_t)resident_vec((int)c->cfg.k);
     *on_chip_per_thread = (sched && c->hybrid) ? std::min<uint32_t>(per, (uint32_t)(hy_reg_items((int)c->cfg.k) + hy_lds_items((int)c->cfg.k))) : per;
   }
   return TSAMD_OK;

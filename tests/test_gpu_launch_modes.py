@@ -129,7 +129,7 @@ def test_modes_a_context_does_not_qualify_for(ts, monkeypatch):
     with ts.Engine(400_000, 4, 20) as eng:         # K = 20 holds 5 individuals per thread in registers: 327 680 per GPU ...
         assert eng.launch_info()["kernels_per_snp"] == 0   # ... above that the whole-schedule kernel is ts_hybrid
         geo = eng.schedule_geometry()
-        assert geo["indivs_per_thread"] == 7 and geo["on_chip_per_thread"] == 7 and geo["workgroups"] == 224, geo
+        assert geo["indivs_per_thread"] == 7 and geo["on_chip_per_thread"] == 7 and geo["workgroups"] == 256, geo
         with pytest.raises(ts.TsamdError):
             eng.set_launch_mode(ts.LAUNCH_PER_SNP)         # (ts_resident has no such variant)
     monkeypatch.setenv("TSAMD_HYBRID", "0")
