@@ -64,7 +64,9 @@ typedef struct tsamd_config {
 
 #define TSAMD_FLAG_SPLIT_EPILOGUE 1u /* run the sharded kernel sequence (pass, row sum, exchange) even on one GPU */
 #define TSAMD_FLAG_NO_GRAPH 2u       /* tsamd_run_schedule launches eagerly instead of replaying a hipGraph */
-#define TSAMD_FLAG_TEST_HOOKS 4u     /* honour the TSAMD_TEST_* environment hooks of the peer-to-peer exchange (tests only) */
+#define TSAMD_FLAG_TEST_HOOKS 4u     /* honour the TSAMD_TEST_* environment hooks (tests only): those of the peer-to-peer exchange, and
+                                        TSAMD_TEST_MAX_WORKGROUPS (the resident kernels' launch geometry as on a device with that
+                                        many compute units: small shards then run the many-items-per-thread paths) */
 
 int tsamd_abi_version(void);
 void tsamd_default_config(tsamd_config *cfg, uint32_t n, uint32_t l, uint32_t k);

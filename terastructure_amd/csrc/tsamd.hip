@@ -802,7 +802,10 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
     // weights fit the register file (resident_items(K) items per thread of a 256-thread workgroup) and every workgroup
     // can be resident at once -- which the kernels verify for themselves at the start of every launch.
     hipDeviceProp_t prop;
-    const int cus = hipGetDeviceProperties(&prop, c->dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    int cus = hipGetDeviceProperties(&prop, c->dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    // (test hook: fewer workgroups than the device holds, so that small shards exercise the many-items-per-thread paths --
+    // ts_hybrid's LDS and streamed items for every K -- at a size the oracle finishes in a moment)
+    if ((cfg->flags & TSAMD_FLAG_TEST_HOOKS) && env_u32("TSAMD_TEST_MAX_WORKGROUPS", 0) > 0u) cus = std::min<int>(cus, (int)env_u32("TSAMD_TEST_MAX_WORKGROUPS", 0));
     c->sched_grid = c->grid;
     c->sched_chunk = p.chunk;
     // (TSAMD_GRID / TSAMD_BLOCK shape the launch-per-pass kernels: a context they are set for runs those)

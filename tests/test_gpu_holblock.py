@@ -203,3 +203,35 @@ def test_block_that_cannot_be_resident_is_replayed(ts, monkeypatch):
         assert eng.total_passes() == sum(its)
         assert_state_close(eng, orc, 1e-9, "blocks again after raising the mode")
     orc.close()
+
+
+@pytest.mark.parametrize("k", list(range(1, 33)))
+def test_every_instantiation_of_the_block(ts, k, monkeypatch):
+    """ts_holblock<K> for EVERY K = 1 ... 32 (batches of 16 ... 4 locations, sub-batches of 4 / 2 / 1) on a shard of a few
+    workgroups: bit for bit the entry-by-entry path, and the oracle at 1e-9"""
+    n, l = 3_000 + 97 * k, 24
+    payload, g, y = data(n, l, k, 7100 + k)
+    vlocs = np.arange(l, dtype=np.uint32)[::-1].copy()
+    outs = []
+    for block in (True, False):
+        monkeypatch.setenv("TSAMD_HOLBLOCK", "1" if block else "0")
+        eng, held = engine(ts, n, l, k, payload, g, y)
+        with eng:
+            eng.run_schedule(TRAIN)
+            eng.run_schedule(vlocs, 1)
+            eng.run_schedule(TRAIN2[:3])
+            eng.synchronize()
+            assert (eng.holblock_info()["launches"] == 1) == block
+            outs.append(snapshot(eng))
+    for x, z in zip(*outs):
+        assert np.array_equal(x, z)
+    orc = op.Oracle(n, l, k)
+    orc.load_bed_payload(payload)
+    orc.set_gamma(g)
+    for loc, ids in held.items():
+        orc.set_heldout(loc, ids)
+    its = [orc.snp_update(int(x)) for x in TRAIN] + [orc.snp_update(int(x), 1) for x in vlocs] + [orc.snp_update(int(x)) for x in TRAIN2[:3]]
+    lam, gam, cn, passes, _ = outs[0]
+    assert passes == sum(its)
+    assert rel_err(lam, orc.lambda_()) < 1e-9 and rel_err(gam, orc.gamma()) < 1e-9 and np.array_equal(cn, orc.c_indiv())
+    orc.close()

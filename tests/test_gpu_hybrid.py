@@ -140,3 +140,45 @@ def test_hybrid_launch_that_cannot_be_resident_is_replayed(ts, monkeypatch):
         assert eng.total_passes() == sum(its) and eng.recoveries() == 1
         assert_state_close(eng, orc, 1e-9, "ts_hybrid raised again")
     orc.close()
+
+
+def _on_chip_items(k):
+    reg = 16 if k <= 8 else 128 // k if k <= 16 else 112 // k if k <= 24 else 3
+    if k > 20:
+        reg -= 1
+    return reg, reg + min(16, (160 * 1024 - 1024 - 200 * k) // (k * 8 * 256))
+
+
+@pytest.mark.parametrize("k", list(range(1, 33)))
+def test_every_instantiation_on_a_small_device(ts, k, monkeypatch):
+    """ts_hybrid<K> for EVERY K = 1 ... 32 -- with and without streamed items -- on four workgroups (TSAMD_TEST_MAX_WORKGROUPS:
+    the geometry of a device with four compute units), so that a few thousand individuals fill the register items, the LDS
+    items and three streamed items of every thread; against the oracle, with validation-mode entries and a repeated location."""
+    monkeypatch.setenv("TSAMD_TEST_MAX_WORKGROUPS", "4")
+    reg, chip = _on_chip_items(k)
+    l = 10
+    locs = np.array([3, 3, 7, 1, 7, 0, 2, 5, 9, 4, 4, 6], dtype=np.uint32)
+    for extra in (3, -1):          # three streamed items per thread / one item short of the on-chip capacity (no streaming)
+        n = 4 * 256 * (chip + extra) - 37
+        if n <= 4 * 256 * reg:     # (K where LDS adds a single item: "one short" is ts_schedule's territory)
+            continue
+        y, _, _ = psd_genotypes(n, l, k, 8300 + k, 0.03)
+        payload = pack_bed(y)
+        g = init_gamma(n, k, 8301 + k)
+        orc = op.Oracle(n, l, k, nthreads=usable_cores() if n * k > 100_000 else 1)
+        orc.load_bed_payload(payload)
+        orc.set_gamma(g)
+        with ts.Engine(n, l, k, flags=ts.FLAG_TEST_HOOKS) as eng:
+            eng.upload_bed(payload)
+            eng.set_gamma(g)
+            geo = eng.schedule_geometry()
+            assert geo["workgroups"] == 4 and geo["on_chip_per_thread"] == min(chip, geo["indivs_per_thread"]), geo
+            assert geo["indivs_per_thread"] == chip + extra and geo["indivs_per_thread"] > reg, geo
+            eng.run_schedule(locs[:7])
+            eng.run_schedule(locs[7:9], 1)
+            eng.run_schedule(locs[9:])
+            eng.synchronize()
+            its = [orc.snp_update(int(x), 1 if 7 <= i < 9 else 0) for i, x in enumerate(locs)]
+            assert eng.total_passes() == sum(its)
+            assert_state_close(eng, orc, 1e-9, f"ts_hybrid<{k}> on four workgroups, {chip + extra} individuals per thread")
+        orc.close()
