@@ -15,8 +15,25 @@
  *     GSL seeding recurrence);
  *   - the reference cannot be built here (GSL absent; a stand-in library is
  *     not allowed), so bit-level trajectories of the real binary are
- *     PARITY UNPINNED: gsl_ran_gamma's ziggurat normal tables and the last
- *     ulp of gsl_sf_psi are not reproducible offline.
+ *     PARITY UNPINNED.  Exactly two GSL behaviours stay unpinned:
+ *       1. the stream of gsl_ran_gamma (init_gamma, src/snpsamplinge.cc:233).
+ *          Real GSL runs Marsaglia-Tsang on normals from
+ *          gsl_ran_gaussian_ziggurat (128-entry tables, extra uniform draws
+ *          on the rejection path); orc_ran_gamma runs the same
+ *          Marsaglia-Tsang recurrence on polar Box-Muller normals.  Same
+ *          distribution, different numbers: the INITIAL gamma differs from a
+ *          real run's (the C ABI takes gamma from the host, so the device
+ *          path is unaffected), and with it every later digit.
+ *       2. the last ulp of gsl_sf_psi (src/lib.hh:29-70,
+ *          src/snpsamplinge.cc:292-294, :734-737).  Real GSL evaluates
+ *          Chebyshev fits (psi_cs / apsi_cs); orc_digamma uses the
+ *          recurrence to x >= 10 plus the asymptotic series -- within 2e-15
+ *          relative of scipy.special.digamma (tested), not bit-identical.
+ *     Everything else the path uses from GSL is pinned by known answers:
+ *     mt19937 seeding (0 -> 4357) / tempering, gsl_rng_uniform_int's
+ *     rejection rule, gsl_sf_fact (exact for the arguments used).
+ *     tests/test_oracle_golden.py::test_config1_regression_on_own_sampler
+ *     is a regression check on this sampler, not a pin to the reference.
  *
  * Every function cites the reference file:line it restates
  * (paths relative to the upstream repository root).

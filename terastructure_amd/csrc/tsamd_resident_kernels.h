@@ -1079,8 +1079,32 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     }
     xcount += 1u;
     const uint32_t tag = xseq0 + xcount;
+#ifdef TSAMD_EXP_L2PF  // (experiment: while the workgroup waits in exchange e of a SNP, touch the gamma / c_n lines of its e-th streamed item)
+    uint32_t pf_dummy = 0u;
+    auto pf = [&]() {
+      const uint32_t e = iters - 1u;
+      uint32_t tsel = 0u, c = 0u;
+#pragma unroll
+      for (int t = 0; t < kItems; ++t)
+        if (!is_lds(t)) {
+          tsel = c == e ? (uint32_t)t : tsel;
+          c += 1u;
+        }
+      if (e < (uint32_t)(kItems - kLds)) {
+        const uint32_t i = item_or_last(tsel);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(p.gam + (size_t)k * np + i) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(p.cnt + i) : "memory");
+      }
+    };
+    const bool xok = res_exchange<KT, WR, kResOneLevelGrid, ResLay<KT>, decltype(pf)>(xb, p, tag, width, mine, g, m, gridDim.x, s_tot, s_alive, tid,
+                                                                                   fail_code(tag, false, par, serial), kResWaitTicks, pf);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf_dummy) : "memory");
+    if (!xok) return false;
+#else
     if (!res_exchange<KT, WR>(xb, p, tag, width, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial), kResWaitTicks))
       return false;
+#endif
 #ifdef TSAMD_SCHED_TIME
     const unsigned long long te0 = wall_clock64();
     tk_xchg += te0 - tx0;
@@ -1174,9 +1198,15 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       WT gs[KT];  // the streamed item in flight (requested one streamed item ahead)
       CT cs;
       auto load_gamma = [&](uint32_t i, WT (&gq)[KT], CT &cq) {
+#ifdef TSAMD_EXP_NOGLOAD  // (experiment, WRONG RESULTS: the gamma step without its loads -- what do they cost?)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) gq[k] = 1.0 + 1.0e-3 * (double)(k + (int)(i & 7u));
+        cq = 5u;
+#else
 #pragma unroll
         for (int k = 0; k < KT; ++k) gq[k] = reinterpret_cast<const WT *>(p.gam + (size_t)k * np)[i];
         cq = reinterpret_cast<const CT *>(p.cnt)[i];
+#endif
       };
       // one individual: update_gamma + update_rho_indiv (src/snpsamplinge.cc:688-719) with nodekappa = 0.5 (the host
       // selects this kernel only then), then the new weights.  An unobserved genotype takes the same instructions
@@ -1273,13 +1303,25 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         } else {
           gamma_one(gv, wcur, pcode, cv);
         }
+#if defined(TSAMD_EXP_PIN_ALL) || defined(TSAMD_EXP_PIN_LDS)  // (experiments: the new weights are formed inside the item loop)
+#ifdef TSAMD_EXP_PIN_LDS
+        if (is_lds(t))
+#endif
+        {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) asm volatile("" : "+v"(wcur[k]));
+        }
+#endif
         if (is_lds(t)) {
           put_lgamma(t, gv, cv);
-        } else if (mine) {
+        }
+#ifndef TSAMD_EXP_NOGSTORE  // (experiment, WRONG RESULTS: the gamma step without its stores)
+        else if (mine) {
 #pragma unroll
           for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = gv[k];
           reinterpret_cast<CT *>(p.cnt)[i] = cv;
         }
+#endif
         put_item(t, wcur);
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -102,11 +102,15 @@ def _fmt(a):  # save_gamma format, src/snpsamplinge.cc:563-572
     return "".join("".join("%.8f\t" % v for v in row) + "\n" for row in a)
 
 
-def test_config1_matches_reference_probe(config1_run):
-    """Numbers the survey recorded from the REAL reference sources on this input
-    (reference built there with the same
-    mt19937 / Marsaglia-Tsang / digamma restatements): validation.txt lines,
-    self-termination at iter 16050 and the md5 of theta.txt."""
+def test_config1_regression_on_own_sampler(config1_run):
+    """REGRESSION CHECK ON THIS BUILD'S OWN SAMPLER -- it pins nothing of the reference binary.
+    The numbers (validation.txt lines, self-termination at iter 16050, md5 of theta.txt) were first
+    recorded by the survey from the reference's sources compiled
+    against header-only stand-ins for GSL that carry the SAME mt19937 / Marsaglia-Tsang (polar normal)
+    / digamma restatements as oracle/ts_oracle.c.  Real GSL draws its normals from a ziggurat and
+    evaluates psi with Chebyshev fits, so a real reference binary starts from another gamma and ends
+    elsewhere in the last digits.  What this test guards: the oracle build (compiler flags, operation
+    order) still reproduces its own recorded run bit for bit."""
     o, res = config1_run
     assert res["stopped"] and res["final_iter"] == 16050
     lines = res["lines"]
@@ -116,6 +120,17 @@ def test_config1_matches_reference_probe(config1_run):
     assert abs(lines[-1][1] - (-0.7314)) < 1e-3
     md5 = hashlib.md5(_fmt(o.theta()).encode()).hexdigest()
     assert md5 == "da9e6e57d6fed4446ead30c8d841e010"
+
+
+def _median_kl(truth, est):
+    """median over individuals of KL(theta_true || theta_est) after the best column permutation -- the accuracy
+    metric of the TeraStructure paper (Gopalan et al. 2016, simulations)"""
+    k = truth.shape[1]
+    perm = min(itertools.permutations(range(k)), key=lambda p: np.mean((est[:, list(p)] - truth) ** 2))
+    p = np.clip(truth, 1e-10, None)
+    q = np.clip(est[:, list(perm)], 1e-10, None)
+    p, q = p / p.sum(1, keepdims=True), q / q.sum(1, keepdims=True)
+    return float(np.median((p * np.log(p / q)).sum(1)))
 
 
 def test_config1_against_reference_fixtures(config1_run):
@@ -129,6 +144,11 @@ def test_config1_against_reference_fixtures(config1_run):
     assert _best_perm_rmse(theta, truth) <= 0.06
     assert _best_perm_rmse(theta, shipped) <= 0.04       # same fit as the authors' run
     assert _best_perm_rmse(shipped, truth) <= 0.06       # sanity of the fixture itself
+    # the paper's metric: median per-individual KL divergence from the simulation truth.  The authors' shipped run
+    # reaches 0.057 on this input, the oracle 0.047; the two fits are 0.007 apart.
+    kl_ours, kl_shipped = _median_kl(truth, theta), _median_kl(truth, shipped)
+    assert kl_ours <= 0.06 and kl_ours <= kl_shipped + 0.01
+    assert _median_kl(shipped, theta) <= 0.015
     # gamma row sums converge to K*alpha + 2L (each step maps S -> (1-rho)S + rho(K alpha + 2L))
     assert np.allclose(o.gamma().sum(1), 3 * (1 / 3) + 2 * 10000, rtol=1e-6)
     # beta: allele coding is flipped w.r.t. oracle_beta.txt (beta.txt == 1 - oracle_beta)
