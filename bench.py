@@ -135,6 +135,7 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
         errs = [None] * world if rank == 0 else None
         dist.gather_object(None if err is None else f"{type(err).__name__}: {err}", errs, dst=0)
         if rank == 0:
+            report.setdefault("errors", {})[mode] = {"what": what, "by_rank": {str(r): m for r, m in enumerate(errs) if m}}
             print(f"[bench] exchange self-test, {mode}: {what} failed on rank(s) "
                   f"{ {r: m for r, m in enumerate(errs) if m} }", file=sys.stderr, flush=True)
 
@@ -158,6 +159,10 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
             try:
                 (tdist.bootstrap_comm if mode == "rccl" else tdist.bootstrap_p2p)(e, dist)
             except Exception as exc:  # noqa: BLE001 -- raised on every rank together
+                # (verbatim in the line: e.g. what RCCL said when it refused the communicator -- `rccl_error` for that candidate)
+                report.setdefault("errors", {})[mode] = {"what": "bootstrap", "message": str(exc)}
+                if mode == "rccl":
+                    report["rccl_error"] = str(exc)
                 if rank == 0:
                     print(f"[bench] exchange self-test, {mode}: {exc}", file=sys.stderr, flush=True)
                 continue
@@ -265,6 +270,517 @@ def choose_exchange(ts, dist, rank, world, local_rank, n, k, theta_shard, gamma_
     if rank == 0:
         print(f"[bench] exchange self-test: {json.dumps(report)}", file=sys.stderr, flush=True)
     return chosen, report
+
+
+def pmc_record_for(n, k, world, want, stale):
+    """the committed counter record for this (N, K, GPUs, mode) -- only when it was collected from the kernels as they are
+    now (hash of the device sources stored with the records, tools/pmc_record.py); stale[0] says why not otherwise"""
+    pmc = os.path.join(ROOT, "profiles", "pass_kernel_pmc.json")
+    try:
+        doc = json.load(open(pmc))
+        from terastructure_amd.build import kernel_sources_sha
+        now, then = kernel_sources_sha(), doc.get("kernel_sources_sha")
+        for rec in doc.get("records", []):
+            if rec.get("n") == n and rec.get("k") == k and rec.get("n_gpus") == world and rec.get("mode", "pass") == want:
+                if then != now:
+                    stale[0] = (f"profiles/pass_kernel_pmc.json was collected from other kernel sources (sha {then}, the tree "
+                                f"has {now}): its traffic / flops / latency figures are NOT used; re-profile "
+                                "(tools/r05/profile.sh) to refresh them")
+                    return {}
+                return rec
+    except Exception:  # noqa: BLE001
+        pass
+    return {}
+
+
+def pass_kernels_roofline(pr, sub_mode, rec, k, sc, read_us, rmw_us):
+    """roofline object of the launch-per-pass / launch-per-SNP kernels from a profile_read dict (HIP events around the first
+    pass and around the plain passes of every SNP): HBM-bound, algorithmic bytes over the launch time.
+    A plain pass is 8*N_shard*K (weights) + N_shard/4 (2-bit column) algorithmic bytes; the first pass (gamma step fused):
+    R w, R gamma, W gamma, W w = 32*N*K; c_n R+W = 8N; two columns = N/2.  The resident kernel (mode "snp") runs ALL plain
+    passes of a SNP in one launch that reads the weights once and keeps them in registers."""
+    if not (pr["pass_launches"] and pr["first_launches"]):
+        return None
+    pass_bytes = 8.0 * sc * k + sc / 4.0
+    first_bytes = 32.0 * sc * k + 8.0 * sc + sc / 2.0
+    resident = sub_mode == "snp"
+    first_s = pr["first_ms"] / pr["first_launches"] * 1e-3
+    first_achieved = first_bytes / first_s / 1e9
+    passes_per_launch = pr["pass_launches"] / pr["first_launches"] if resident else 1.0
+    launches = pr["first_launches"] if resident else pr["pass_launches"]
+    avg_s = pr["pass_ms"] / launches * 1e-3
+    alg_bytes = passes_per_launch * pass_bytes
+    equiv = None
+    if resident:
+        # the resident kernel reads the weights from memory ONCE per SNP and runs the later passes from registers:
+        # its memory roofline is what it must move (weights once, one column), not passes x the plain-pass bytes
+        equiv = {"bytes_per_launch": alg_bytes, "GBps": round(alg_bytes / avg_s / 1e9, 1),
+                 "note": "passes x (8NK + N/4), the reference's dataflow, over this kernel's time: not a fraction of any peak"}
+        alg_bytes = pass_bytes
+        kernel = (f"ts_resident<{k}> (all {passes_per_launch:.3g} plain passes of a SNP in one launch: weights read once, "
+                  "kept in registers; partial rows exchanged inside the launch)")
+        note = ("achieved = the bytes the kernel must move per launch (the N x K weights once + one 2-bit column) over its "
+                "launch time; `traffic` is the counter figure.  It is bound by neither memory nor arithmetic but by the "
+                "in-launch exchange (about 3 us per pass with the ALU idle) plus the fp64 sweeps (2.6 us per pass at N = 1M, "
+                "K = 8): per_pass_us x passes = avg_launch_us.  probe_read_us is a bare streaming read of the weights on this "
+                "box (tsamd_probe_stream).")
+    else:
+        kernel = f"ts_pass<{k},false> (plain pass, max_inner - 1 launches per update)"
+        note = ("fabric-side bandwidth incl. Infinity Cache, not DRAM bandwidth: the pass re-reads the same weights (8NK "
+                "bytes: 64 MB at N=1M, K=8) every launch and they stay in the 256 MiB Infinity Cache; FETCH_SIZE counts "
+                "those hits.  probe_read_us is a bare streaming read of the same array with the same geometry on this "
+                "box (tsamd_probe_stream): the second denominator.")
+    achieved = alg_bytes / avg_s / 1e9
+    return {
+        "bound": "hbm", "kernel": kernel,
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("hbm_bytes_per_launch"),
+        "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bandwidth_equiv": equiv,
+        "avg_launch_us": round(avg_s * 1e6, 3), "launches_timed": launches,
+        "passes_per_launch": round(passes_per_launch, 3),
+        "per_pass_us": round(avg_s * 1e6 / passes_per_launch, 3),
+        "ceiling_note": note,
+        "probe_read_us": None if read_us is None else round(read_us, 3),
+        "frac_of_probe": None if read_us is None else round(read_us * 1e-6 / avg_s, 4),
+        "first_pass": {
+            "kernel": f"ts_pass<{k},true> (first pass of a SNP + the previous SNP's gamma step, 1 launch per update)",
+            "bound": "hbm", "achieved": round(first_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(first_achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("first_pass_hbm_bytes_per_launch"),
+            "algorithmic_bytes_per_launch": first_bytes, "avg_launch_us": round(first_s * 1e6, 3),
+            "launches_timed": pr["first_launches"],
+            "probe_rmw_us": None if rmw_us is None else round(rmw_us, 3),
+            "frac_of_probe": None if rmw_us is None else round(rmw_us * 1e-6 / first_s, 4),
+        },
+    }
+
+
+def schedule_roofline(prs, ran, nsteps, rec, stale, k, sc, geo, read_us):
+    """roofline object of the whole-schedule kernel (ts_schedule, or ts_hybrid above the register capacity) from the HIP
+    events around its launches (prs), the passes the device ran (ran) over nsteps updates, and -- when one is committed
+    for this shape -- the counter record rec.  sc = individuals of this rank's shard; figures are per GPU."""
+    if not prs["pass_launches"]:
+        return None
+    pass_bytes = 8.0 * sc * k + sc / 4.0
+    first_bytes = 32.0 * sc * k + 8.0 * sc + sc / 2.0
+    launch_s = prs["pass_ms"] / prs["pass_launches"] * 1e-3
+    upd = nsteps / prs["pass_launches"]
+    ppu = ran / nsteps                                   # passes per update
+    # (1) what binds it: fp64 vector arithmetic at one wave per SIMD.  Flops per update from the SQ counters of
+    # a profiled launch when a record for this (N, K) is committed (profiles/pass_kernel_pmc.json, built from
+    # rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64), else the hand count of the kernel's own
+    # formulation (FMA = 2): a sweep is 8K + 12 per individual (two K-term normalisers, ONE reciprocal of their
+    # product with its third-order step, 2K accumulations per parent), the gamma step 89K + 25 (normalisers 4K,
+    # update 7K -- 10K in the full-size K <= 8 instantiation, which keeps the literal form --, exp(psi) 78K).
+    literal_step = k <= 8 and sc > 15 * 65536
+    hand = ppu * sc * (8.0 * k + 12.0) + sc * ((92.0 if literal_step else 89.0) * k + 25.0)
+    flops = rec.get("fp64_flops_per_update")
+    if flops:
+        flops_src = ("SQ_INSTS_VALU_*_F64 counters of a profiled launch committed under profiles/ (constants of "
+                     "profiles/pass_kernel_pmc.json, guarded by a hash of the kernel sources -- not measured in this run): "
+                     + ", ".join(rec.get("flops_source_files", [])))
+    else:
+        flops = hand
+        flops_src = ("hand count of the kernel's formulation (" + (stale[0] or "no counter record for this N, K, GPU count in "
+                     "profiles/pass_kernel_pmc.json") + ")")
+    tflops = flops * upd / launch_s / 1e12
+    # (2) memory: what the kernel itself must move per update -- gamma and c_n, read and written, of the items
+    # whose gamma is not kept in LDS, one 2-bit column -- and what the counters saw
+    vec, items, n_lds = resident_geometry(k)
+    moved = (16.0 * sc * k + 8.0 * sc) * (items - n_lds) / items + sc / 4.0
+    traffic = rec.get("hbm_bytes_per_update")
+    # (3) the reference's dataflow (SURVEY 8d): per update one first pass 32NK + 8N + N/2 and passes - 1 plain
+    # passes 8NK + N/4 -- what this kernel would have to move if the weights did not stay in registers
+    alg_bytes = (nsteps * first_bytes + max(0, ran - nsteps) * pass_bytes) / prs["pass_launches"]
+    # (4) latency: the in-launch exchanges, during which the vector ALU idles (in-kernel timers of the
+    # diagnostic build -DTSAMD_SCHED_TIME, recorded with the counters)
+    xus = rec.get("exchange_us_per_update")
+    roofline = {
+        "bound": "fp64_valu",
+        "kernel": (f"ts_schedule<{k}> (one launch = {upd:.0f} SNP updates: the gamma step and all {ppu:.3g} passes of every "
+                   "SNP; weights in registers from the first SNP to the last; partial rows exchanged inside the launch)"),
+        "achieved": round(tflops, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4),
+        "traffic": None if traffic is None else traffic * upd,
+        "flops_per_update": flops, "flops_per_update_hand_count": hand, "flops_source": flops_src,
+        "measured_in_this_run": "avg_launch_us (HIP events on the engine's stream around every launch of the timed kernel)",
+        "avg_launch_us": round(launch_s * 1e6, 1), "launches_timed": prs["pass_launches"], "updates_per_launch": upd,
+        "per_update_us": round(launch_s * 1e6 / upd, 3), "passes_per_update": round(ppu, 3),
+        "bound_note": ("fp64 vector issue: the kernel runs one wave per SIMD (a thread owns the whole register file), where "
+                       "tools/fma_probe reaches 62.5 of the 78.6 TFLOP/s; the rest of the distance is the exchange latency "
+                       "(`latency`) and instructions that are not flops (register moves between the AGPR-resident weights "
+                       "and the ALU, code decode): every vector instruction costs the lone wave 4.3-4.7 cycles, "
+                       "tools/ubench/op_cost.hip.  HBM is far from binding (`hbm`)."),
+        "hbm": {
+            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "achieved": None if traffic is None else round(traffic * upd / launch_s / 1e9, 1),
+            "frac": None if traffic is None else round(traffic * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic_bytes_per_update": traffic,
+            "moved_bytes_per_update": moved, "moved_GBps": round(moved * upd / launch_s / 1e9, 1),
+            "moved_frac": round(moved * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+            "note": ("achieved / frac: FETCH_SIZE x 2 + WRITE_SIZE of a profiled launch (profiles/pass_kernel_pmc.json) over "
+                     "this run's launch time; moved_*: the bytes the kernel must move by construction (streamed gamma "
+                     "read + write, c_n, one 2-bit column)"),
+        },
+        "algorithmic_bandwidth_equiv": {
+            "bytes_per_update": alg_bytes / upd, "GBps": round(alg_bytes / launch_s / 1e9, 1),
+            "note": ("SURVEY 8(d) bytes of the reference's dataflow (every pass re-reads the N x K weights) over this kernel's "
+                     "time: a speed-up figure against a memory-bound implementation, not a fraction of any peak -- the "
+                     "kernel does not move these bytes"),
+        },
+        "latency": {
+            "exchanges_per_update": round(ppu, 3),
+            "exchange_us_per_update": xus,
+            "frac_of_update": None if xus is None else round(xus / (launch_s * 1e6 / upd), 4),
+            "source": rec.get("exchange_source", "no in-kernel timer record for this N, K"),
+        },
+        "launch_per_snp": None, "first_pass": None,
+        "probe_read_us": None if read_us is None else round(read_us, 3),
+    }
+    # A shard above ts_schedule's register capacity runs the same one-launch structure as ts_hybrid: part of the
+    # weights in registers + LDS, the rest re-read from memory every pass, all of gamma streamed -- that kernel is
+    # bound by memory, and priced so: the bytes it must move by construction over the launch time against the HBM peak.
+    if geo and geo["indivs_per_thread"] > items:
+        on_chip = min(sc, geo["workgroups"] * 256 * geo["on_chip_per_thread"])
+        streamed = sc - on_chip
+        moved_h = ppu * streamed * 8.0 * k + sc * (16.0 * k + 8.0) + streamed * 16.0 * k + (ppu + 1.0) * sc / 4.0
+        kernel_h = (f"ts_hybrid<{k}> (one launch = {upd:.0f} SNP updates; of a thread's {geo['indivs_per_thread']} individuals "
+                    f"{geo['on_chip_per_thread']} keep their weights in registers + LDS for the whole launch, the weights of the "
+                    "others are re-read every pass; gamma and c_n of all stream through the gamma step)")
+        hbm_h = {"bound": "hbm", "achieved": round(moved_h * upd / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(moved_h * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_update": moved_h,
+                 "algorithmic_bytes_note": ("passes x streamed individuals x 8K (weights re-read) + N (16K + 8) (gamma, c_n read and "
+                                            "written) + streamed x 16K (their weights read and written by the gamma step) + "
+                                            "(passes + 1) N / 4 (columns)"),
+                 "streamed_individuals": int(streamed), "on_chip_individuals": int(on_chip)}
+        if streamed > 0:   # memory binds: the streamed weights and the gamma step's streams
+            fp64 = {key: roofline[key] for key in ("achieved", "peak", "unit", "frac", "flops_per_update", "flops_per_update_hand_count",
+                                                   "flops_source")}
+            fp64["bound"] = "fp64_valu"
+            roofline.update(hbm_h)
+            roofline.update({
+                "kernel": kernel_h, "fp64_valu": fp64,
+                "bound_note": ("memory: the streamed weights (Infinity Cache / HBM) and the gamma step's streams; the exchanges and "
+                               "epilogues (`latency`) run with the memory system idle"),
+            })
+        else:              # everything on chip: like ts_schedule, with all of gamma streamed through the gamma step
+            roofline["kernel"] = kernel_h
+            roofline["hbm"] = hbm_h
+        roofline["traffic"] = None if not rec.get("hbm_bytes_per_update") else rec["hbm_bytes_per_update"] * upd
+    return roofline
+
+
+def measure_legs(args, ts, eng, dist, rank, world, local_rank, n, l, k, sc, locs, cores, oracle_ok, gamma_init):
+    """Everything the JSON line carries besides `value`, measured after the timed region: the roofline of the TIMED kernel
+    (HIP events around its launches, in the mode that was timed -- no mode switch), then the secondary legs -- the kernels
+    of the other launch modes, the device-copy ceiling, the validation block, the CPU baseline and the GPU's parity with it.
+    Every leg runs in its own try: one that fails (a peer timing out in a rehearsal with all ranks on one GPU, a mode the
+    context does not qualify for) is recorded in `legs` and cannot null the others.  N > 1: every rank runs every leg, and a
+    leg counts as done only if it succeeded on EVERY rank (one all_ok collective per leg keeps the ranks aligned); after a
+    failed leg that ran kernels of a sharded context -- whose state may be void then -- the remaining GPU legs are skipped."""
+    from terastructure_amd import dist as tdist
+
+    legs = {}
+    usable = [True]   # the engine is still good for GPU legs
+
+    def leg(name, fn, gpu=True):
+        if gpu and not usable[0]:
+            legs[name] = "skipped: an earlier leg left the context unusable"
+            return None
+        out, err = None, None
+        try:
+            out = fn()
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+        ok = err is None
+        if dist is not None:
+            ok = tdist.all_ok(ok, dist)
+        if ok:
+            legs[name] = "ok"
+            return out
+        legs[name] = f"failed: {type(err).__name__}: {err}" if err is not None else "failed on a peer rank"
+        print(f"[bench] leg {name} {legs[name]}; the line is reported without it", file=sys.stderr, flush=True)
+        if gpu:
+            if dist is not None:
+                usable[0] = False   # (a sharded context: the peers' states may have diverged -- no further kernels)
+            else:
+                try:
+                    eng.synchronize()
+                except Exception:  # noqa: BLE001
+                    usable[0] = False
+        return None
+
+    info = eng.launch_info()
+    kps = info["kernels_per_snp"]
+    mode = "schedule" if kps == 0 else "snp" if (kps == 2 and eng.cfg.max_inner > 2) else "pass"
+    stale = [None]  # why the committed counter records were not used (None: they were, or there are none for this shape)
+    warm = args.warmup
+
+    def profiled(nsteps):
+        """(profile_read dict, passes the device ran) over nsteps updates"""
+        eng.synchronize()
+        q0 = eng.total_passes()
+        eng.profile_enable(True)
+        try:
+            eng.run_schedule(locs[warm:warm + nsteps])
+            eng.synchronize()
+            pr_ = eng.profile_read()
+        finally:
+            eng.profile_enable(False)
+        return pr_, eng.total_passes() - q0
+
+    roofline = None
+    read_us = rmw_us = None
+    if not args.no_profile:
+        probe = leg("stream_probe", lambda: eng.probe_stream(50), gpu=False)   # (rank-local kernels: no peer is involved)
+        if probe is not None:
+            read_us, rmw_us = probe
+
+        # ---- the timed kernel, in the mode that was timed -----------------------------------
+        def timed_kernel():
+            if mode == "schedule":
+                nsteps = min(args.steps, 2000)
+                prs, ran = profiled(nsteps)
+                try:
+                    geo = eng.schedule_geometry()
+                except Exception:  # noqa: BLE001
+                    geo = None
+                return schedule_roofline(prs, ran, nsteps, pmc_record_for(n, k, world, "schedule", stale), stale, k, sc, geo, read_us)
+            pr, _ = profiled(min(args.steps, 300))
+            return pass_kernels_roofline(pr, mode, pmc_record_for(n, k, world, mode, stale), k, sc, read_us, rmw_us)
+
+        roofline = leg("roofline_timed_kernel", timed_kernel)
+
+        # ---- secondary: the kernels of the launch-per-SNP / launch-per-pass sequence, one GPU only (a sharded context is
+        # not switched between modes for a measurement: its other sequence waits on peers with its own bounded protocol)
+        if roofline is not None and mode == "schedule" and world == 1:
+            def other_modes():
+                sub = ts.LAUNCH_PER_SNP
+                try:
+                    eng.set_launch_mode(sub)
+                except ts.TsamdError:       # (a shard above the register capacity -- ts_hybrid -- has no launch-per-SNP mode)
+                    sub = ts.LAUNCH_PER_PASS
+                    eng.set_launch_mode(sub)
+                try:
+                    pr, _ = profiled(min(args.steps, 300))
+                finally:
+                    eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+                sub_mode = "snp" if (sub == ts.LAUNCH_PER_SNP and eng.cfg.max_inner > 2) else "pass"
+                return pass_kernels_roofline(pr, sub_mode, pmc_record_for(n, k, world, sub_mode, stale), k, sc, read_us, rmw_us)
+
+            per_snp = leg("roofline_other_launch_modes", other_modes)
+            if per_snp is not None:
+                roofline["launch_per_snp"] = per_snp
+                roofline["first_pass"] = per_snp["first_pass"]
+        if roofline is not None:
+            roofline["counter_records"] = stale[0] or ("profiles/pass_kernel_pmc.json matches the kernel sources of this tree (or holds no "
+                                                       "record for this shape)")
+
+        # third denominator (SURVEY 8d): what a plain device-to-device copy reaches on this box,
+        # with the benchmark's data still resident (read + write bytes over the copy time)
+        def device_copy():
+            import torch
+
+            dev = torch.device("cuda", local_rank)
+            src = torch.empty(1 << 27, dtype=torch.float64, device=dev)  # 1 GiB
+            dst = torch.empty_like(src)
+            src.zero_()
+            for _ in range(2):
+                dst.copy_(src)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            ev1.record()
+            torch.cuda.synchronize(dev)
+            return round(10 * 2 * src.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
+
+        if roofline is not None:
+            roofline["device_copy_GBps"] = leg("device_copy", device_copy, gpu=False)
+
+    # ---- CPU baseline: the oracle ("port") on the host cores of rank 0, bounded sample; then the GPU(s) ----
+    # ---- repeat exactly those updates from the same start and the two states are compared ----
+    cpu, parity = None, None
+    if args.cpu_seconds > 0:
+        ls = 8  # sample columns; per-update cost does not depend on L
+        box = {}
+
+        # RULE of this function: a leg's body does only work that can fail on ONE rank alone (kernels, copies, the oracle);
+        # torch.distributed collectives stand OUTSIDE the legs, after the leg's own all_ok -- every rank reaches them or none.
+        cols = leg("sample_columns", lambda: np.stack([eng.download_bed(int(j)) for j in range(ls)]), gpu=False)
+        got = None
+        if cols is not None:
+            # (the shards' byte ranges of a column are contiguous slices of the .bed column: tsamd_shard_range)
+            if dist is not None:
+                parts = gather_bytes(cols, dist, rank)
+                cols = np.concatenate(parts, axis=1)[:, :(n + 3) // 4] if rank == 0 else None
+
+            def cpu_baseline():
+                if rank != 0:
+                    return None
+                if not oracle_ok:
+                    raise RuntimeError("oracle/libts_oracle.so is not available")
+                import oracle_py as op
+
+                g0 = gamma_init()
+
+                def run_oracle(threads, budget, max_updates):
+                    orc = op.Oracle(n, ls, k, nthreads=threads, gamma_scale=float(l))
+                    orc.load_bed_payload(cols)
+                    orc.set_gamma(g0)
+                    seq = [0]
+                    orc.snp_update(0)  # untimed: the first call has no gamma step to apply
+                    done, tc0 = 0, time.perf_counter()
+                    while True:
+                        seq.append((done + 1) % ls)
+                        orc.snp_update(seq[-1])
+                        done += 1
+                        if time.perf_counter() - tc0 > budget or done >= max_updates:
+                            break
+                    return orc, seq, done, time.perf_counter() - tc0
+
+                orc, seq, done, cdt = run_oracle(cores, args.cpu_seconds * 0.75, args.steps)
+                box["want"] = (orc.lambda_(), orc.gamma(), orc.c_indiv())
+                orc.close()
+                orc1, _, done1, cdt1 = run_oracle(1, args.cpu_seconds * 0.25, 4)
+                orc1.close()
+                return (seq, {"value": round(done / cdt, 4), "unit": "SNP-minibatch updates/s", "cores": cores,
+                              "kind": "port", "value_1_thread": round(done1 / cdt1, 4),
+                              "sample": f"{done} updates (10 passes + gamma step each) at N={n}, K={k} on {ls} of the "
+                                        f"benchmark's own columns, oracle/ts_oracle.c with {cores} OpenMP threads "
+                                        f"in the reference's work partition on rank 0's host (it shows {os.cpu_count()} CPUs, "
+                                        f"{cores} usable under its affinity mask / cgroup quota); value_1_thread: "
+                                        f"{done1} updates with one thread"})
+
+            got = leg("cpu_baseline", cpu_baseline, gpu=False)
+            if legs["cpu_baseline"] == "ok" and dist is not None:   # (the other ranks need the sequence the oracle ran)
+                res = [got]
+                dist.broadcast_object_list(res, src=0)
+                got = res[0]
+        if got is not None:
+            seq, cpu = got
+            # the same updates on the GPU(s), from the same state (lambda of the sample columns back to eta, gamma and c_n
+            # back to the start, no pending step), through the timed entry point -- in the mode that was timed and, on one
+            # GPU, in every other launch mode whose kernels this line publishes timings of
+            eta = np.ones((k, 2))
+            sb = eng.shard_begin
+
+            def gpu_repeat():
+                for j in range(ls):
+                    eng.set_lambda(j, eta)
+                eng.set_gamma(gamma_init()[sb:sb + sc])
+                eng.set_counts(np.zeros(sc, dtype=np.uint32))
+                eng.clear_pending()
+                eng.run_schedule(np.array(seq, dtype=np.uint32))
+                eng.synchronize()
+                return eng.get_lambda(0, ls), eng.get_gamma(), eng.get_counts()
+
+            def compare(state):
+                """rank 0: the (gathered) state against the oracle's"""
+                lam, gam, cnt = state
+                if dist is not None:
+                    gam = tdist.gather_rows(gam, n, dist, ts.shard_range)
+                    cnt = tdist.gather_rows(cnt.astype(np.float64)[:, None], n, dist, ts.shard_range)[:, 0]
+                if rank != 0:
+                    return {}
+                want = box["want"]
+                e_lam, e_gam = rel_err(lam, want[0]), rel_err(gam, want[1])
+                cnt_eq = bool(np.array_equal(cnt, want[2]))
+                return {"lambda_rel_err": e_lam, "gamma_rel_err": e_gam, "c_n_equal": cnt_eq,
+                        "ok": bool(e_lam < 1e-9 and e_gam < 1e-9 and cnt_eq)}
+
+            state = leg("parity_vs_cpu_baseline", gpu_repeat)
+            if state is not None:
+                parity = compare(state)
+                timed_kps = eng.launch_info()["kernels_per_snp"]
+                parity.update({"updates": len(seq), "tolerance": 1e-9, "kernels_per_snp": timed_kps})
+                if world == 1:
+                    def other_modes_parity():
+                        others = {}
+                        try:
+                            for name, m_ in (("launch_per_snp", ts.LAUNCH_PER_SNP), ("launch_per_pass", ts.LAUNCH_PER_PASS)):
+                                try:
+                                    eng.set_launch_mode(m_)
+                                except ts.TsamdError:
+                                    continue                                  # the context does not qualify for it
+                                if eng.launch_info()["kernels_per_snp"] != timed_kps:
+                                    others[name] = compare(gpu_repeat())
+                                    others[name]["kernels_per_snp"] = eng.launch_info()["kernels_per_snp"]
+                        finally:
+                            try:
+                                eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+                            except ts.TsamdError:
+                                pass
+                        return others
+
+                    others = leg("parity_other_launch_modes", other_modes_parity)
+                    if others:
+                        parity["other_launch_modes"] = others
+                        parity["ok"] = bool(parity["ok"] and all(o["ok"] for o in others.values()))
+    # ---- the validation block (compute_likelihood, src/snpsamplinge.cc:461-544) at this configuration: the reference's sample
+    # (floor(0.005 L) locations x N/100 held-out individuals, src/snpsamplinge.cc:196-224) registered through tsamd_set_heldout,
+    # reports through tsamd_heldout_eval -- batched (ts_holblock) and, for comparison, entry by entry (TSAMD_HOLBLOCK=0).
+    # Not part of `value`: a report runs once per -rfreq training updates.  N > 1: every rank registers the same sample (global
+    # individual ids; a rank keeps its own), the ranks' sums and counts are added.
+    validation = None
+    nval = min(5000, l // 200) if args.validation_locs < 0 else min(args.validation_locs, l - 8)
+    if nval >= 2 and not args.no_profile:
+        def validation_block():
+            if world == 1:
+                try:
+                    eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+                except ts.TsamdError:
+                    pass
+            vrng = np.random.default_rng(args.seed + 77)
+            vlocs = np.sort(8 + vrng.choice(l - 8, size=nval, replace=False)).astype(np.uint32)
+            per_loc = n // 10 if n < 2000 else n // 100
+            tv0 = time.perf_counter()
+            for loc in vlocs:
+                eng.set_heldout(int(loc), np.sort(vrng.choice(n, size=per_loc, replace=False)).astype(np.uint32))
+            t_set = time.perf_counter() - tv0
+            train = vrng.integers(0, l, size=64).astype(np.uint32)
+
+            def report():
+                eng.run_schedule(train)        # (a report follows training: its first entry applies the pending gamma step)
+                eng.synchronize()
+                tq = time.perf_counter()
+                sq, cq, _, _ = eng.heldout_eval(vlocs, run_updates=True)
+                return time.perf_counter() - tq, sq, int(cq)
+
+            report()
+            batched = sorted(report() for _ in range(3))[1]
+            hinfo = eng.holblock_info()
+            os.environ["TSAMD_HOLBLOCK"] = "0"
+            try:
+                single = report()
+            finally:
+                del os.environ["TSAMD_HOLBLOCK"]
+            tq = time.perf_counter()
+            eng.heldout_eval(vlocs, run_updates=False)
+            t_eval = time.perf_counter() - tq
+            return dict(batched=batched, single=single, t_eval=t_eval, t_set=t_set, per_loc=per_loc, batch=hinfo["batch"])
+
+        v = leg("validation_block", validation_block)
+        if v is not None:
+            batched, single = v["batched"], v["single"]
+            if dist is not None:   # this shard's sums / counts / wall times -> the run's
+                sq, cq = tdist.sum_over_ranks([batched[1], float(batched[2])], dist)
+                batched = (tdist.max_over_ranks(batched[0], dist), sq, int(cq))
+                single = (tdist.max_over_ranks(single[0], dist), single[1], single[2])
+            validation = {
+                "locations": int(nval), "heldout_per_location": int(v["per_loc"]), "heldout_entries": int(batched[2]),
+                "kernel": (f"ts_holblock<{k}>: {v['batch']} locations per sweep group and exchange" if v["batch"] else
+                           "entry by entry (the context does not run the batched validation kernel)"),
+                "seconds_per_report": round(batched[0], 4), "us_per_location": round(batched[0] / nval * 1e6, 2),
+                "entry_by_entry_seconds_per_report": round(single[0], 4),
+                "entry_by_entry_us_per_location": round(single[0] / nval * 1e6, 2),
+                "evaluation_only_seconds": round(v["t_eval"], 4),
+                "mean_loglik": round(batched[1] / max(1, batched[2]), 6),
+                "set_heldout_seconds": round(v["t_set"], 2),
+                "note": ("one report = hol-mode updates of all validation locations (theta frozen: batched) + the held-out "
+                         "log-likelihood of all entries; wall time of tsamd_heldout_eval (max over ranks), median of three"),
+            }
+
+    return {"roofline": roofline, "cpu_baseline": cpu, "parity": parity if rank == 0 else None, "validation_block": validation, "legs": legs}
 
 
 def main():
@@ -441,404 +957,8 @@ def main():
     value = args.steps / dt
     mean_passes = passes / max(1, args.steps)
 
-    # ---- roofline of the pass kernels ----------------------------------------------------
-    # a plain pass is 8*N_shard*K (weights) + N_shard/4 (2-bit column) algorithmic bytes;
-    # the first pass (gamma step fused): R w, R gamma, W gamma, W w = 32*N*K; c_n R+W = 8N; two columns = N/2.
-    # With one launch per pass the dominant kernel is the plain pass (9 of 10 launches); with the resident
-    # kernel (single GPU, K <= 32, shards that fit the register file) ALL plain passes of a SNP are one launch that reads the weights
-    # once and keeps them in registers: its algorithmic bytes per launch are passes x the plain-pass bytes.
-    roofline = None
-    if not args.no_profile:
-      try:
-          info = eng.launch_info()
-          kps = info["kernels_per_snp"]
-          mode = "schedule" if kps == 0 else "snp" if (kps == 2 and eng.cfg.max_inner > 2) else "pass"
-          pass_bytes = 8.0 * sc * k + sc / 4.0
-          first_bytes = 32.0 * sc * k + 8.0 * sc + sc / 2.0
-
-          pmc_stale = [None]  # why the committed counter records were not used (None: they were, or there are none for this shape)
-
-          def pmc_record(want):
-              """the committed counter record for this (N, K, mode) -- only when it was collected from the kernels as they are
-              now (hash of the device sources stored with the records, tools/pmc_record.py)"""
-              pmc = os.path.join(ROOT, "profiles", "pass_kernel_pmc.json")
-              try:
-                  doc = json.load(open(pmc))
-                  from terastructure_amd.build import kernel_sources_sha
-                  now, then = kernel_sources_sha(), doc.get("kernel_sources_sha")
-                  for rec in doc.get("records", []):
-                      if rec.get("n") == n and rec.get("k") == k and rec.get("n_gpus") == world and rec.get("mode", "pass") == want:
-                          if then != now:
-                              pmc_stale[0] = (f"profiles/pass_kernel_pmc.json was collected from other kernel sources (sha {then}, the tree "
-                                              f"has {now}): its traffic / flops / latency figures are NOT used; re-profile "
-                                              "(tools/profile_round.sh) to refresh them")
-                              return {}
-                          return rec
-              except Exception:  # noqa: BLE001
-                  pass
-              return {}
-
-          def profiled(nsteps):
-              """(profile_read dict, passes the device ran) over nsteps updates"""
-              eng.synchronize()
-              q0 = eng.total_passes()
-              eng.profile_enable(True)
-              eng.run_schedule(locs[args.warmup:args.warmup + nsteps])
-              eng.synchronize()
-              pr_ = eng.profile_read()
-              eng.profile_enable(False)
-              return pr_, eng.total_passes() - q0
-
-          try:
-              read_us, rmw_us = eng.probe_stream(50)
-          except Exception as exc:  # noqa: BLE001 -- an extra, never fatal
-              read_us = rmw_us = None
-              print(f"[bench] stream probe skipped: {exc}", file=sys.stderr, flush=True)
-
-          # the kernels of the launch-per-SNP / launch-per-pass sequence (the default mode for K > 8, sharded runs and
-          # shards beyond ~1M individuals; with the whole-schedule kernel they are timed in LAUNCH_PER_SNP mode, switched
-          # to for this measurement only)
-          per_snp = None
-          if mode == "schedule":
-              # (a sharded context has no launch-per-SNP mode, and neither has a shard above the register capacity -- ts_hybrid:
-              # their other sequence is one launch per pass)
-              sub = ts.LAUNCH_PER_SNP if world == 1 else ts.LAUNCH_PER_PASS
-              try:
-                  eng.set_launch_mode(sub)
-              except ts.TsamdError:
-                  sub = ts.LAUNCH_PER_PASS
-                  eng.set_launch_mode(sub)
-              try:
-                  pr, _ = profiled(min(args.steps, 300))
-              finally:
-                  eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
-              sub_mode = "snp" if (sub == ts.LAUNCH_PER_SNP and eng.cfg.max_inner > 2) else "pass"
-          else:
-              pr, _ = profiled(min(args.steps, 300))
-              sub_mode = mode
-          if pr["pass_launches"] and pr["first_launches"]:
-              resident = sub_mode == "snp"
-              rec = pmc_record(sub_mode)
-              first_s = pr["first_ms"] / pr["first_launches"] * 1e-3
-              first_achieved = first_bytes / first_s / 1e9
-              passes_per_launch = pr["pass_launches"] / pr["first_launches"] if resident else 1.0
-              launches = pr["first_launches"] if resident else pr["pass_launches"]
-              avg_s = pr["pass_ms"] / launches * 1e-3
-              alg_bytes = passes_per_launch * pass_bytes
-              equiv = None
-              if resident:
-                  # the resident kernel reads the weights from memory ONCE per SNP and runs the later passes from registers:
-                  # its memory roofline is what it must move (weights once, one column), not passes x the plain-pass bytes
-                  equiv = {"bytes_per_launch": alg_bytes, "GBps": round(alg_bytes / avg_s / 1e9, 1),
-                           "note": "passes x (8NK + N/4), the reference's dataflow, over this kernel's time: not a fraction of any peak"}
-                  alg_bytes = pass_bytes
-                  kernel = (f"ts_resident<{k}> (all {passes_per_launch:.3g} plain passes of a SNP in one launch: weights read once, "
-                            "kept in registers; partial rows exchanged inside the launch)")
-                  note = ("achieved = the bytes the kernel must move per launch (the N x K weights once + one 2-bit column) over its "
-                          "launch time; `traffic` is the counter figure.  It is bound by neither memory nor arithmetic but by the "
-                          "in-launch exchange (about 3 us per pass with the ALU idle) plus the fp64 sweeps (2.6 us per pass at N = 1M, "
-                          "K = 8): per_pass_us x passes = avg_launch_us.  probe_read_us is a bare streaming read of the weights on this "
-                          "box (tsamd_probe_stream).")
-              else:
-                  kernel = f"ts_pass<{k},false> (plain pass, max_inner - 1 launches per update)"
-                  note = ("fabric-side bandwidth incl. Infinity Cache, not DRAM bandwidth: the pass re-reads the same weights (8NK "
-                          "bytes: 64 MB at N=1M, K=8) every launch and they stay in the 256 MiB Infinity Cache; FETCH_SIZE counts "
-                          "those hits.  probe_read_us is a bare streaming read of the same array with the same geometry on this "
-                          "box (tsamd_probe_stream): the second denominator.")
-              achieved = alg_bytes / avg_s / 1e9
-              per_snp = {
-                  "bound": "hbm", "kernel": kernel,
-                  "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("hbm_bytes_per_launch"),
-                  "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bandwidth_equiv": equiv,
-                  "avg_launch_us": round(avg_s * 1e6, 3), "launches_timed": launches,
-                  "passes_per_launch": round(passes_per_launch, 3),
-                  "per_pass_us": round(avg_s * 1e6 / passes_per_launch, 3),
-                  "ceiling_note": note,
-                  "probe_read_us": None if read_us is None else round(read_us, 3),
-                  "frac_of_probe": None if read_us is None else round(read_us * 1e-6 / avg_s, 4),
-                  "first_pass": {
-                      "kernel": f"ts_pass<{k},true> (first pass of a SNP + the previous SNP's gamma step, 1 launch per update)",
-                      "bound": "hbm", "achieved": round(first_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(first_achieved / HBM_PEAK_GBS, 4), "traffic": rec.get("first_pass_hbm_bytes_per_launch"),
-                      "algorithmic_bytes_per_launch": first_bytes, "avg_launch_us": round(first_s * 1e6, 3),
-                      "launches_timed": pr["first_launches"],
-                      "probe_rmw_us": None if rmw_us is None else round(rmw_us, 3),
-                      "frac_of_probe": None if rmw_us is None else round(rmw_us * 1e-6 / first_s, 4),
-                  },
-              }
-          if mode == "schedule":
-              # the dominant (only) kernel of the timed region: ONE launch runs the whole schedule.
-              nsteps = min(args.steps, 2000)
-              prs, ran = profiled(nsteps)
-              if prs["pass_launches"]:
-                  rec = pmc_record("schedule")
-                  launch_s = prs["pass_ms"] / prs["pass_launches"] * 1e-3
-                  upd = nsteps / prs["pass_launches"]
-                  ppu = ran / nsteps                                   # passes per update
-                  # (1) what binds it: fp64 vector arithmetic at one wave per SIMD.  Flops per update from the SQ counters of
-                  # a profiled launch when a record for this (N, K) is committed (profiles/pass_kernel_pmc.json, built from
-                  # rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64), else the hand count of the kernel's own
-                  # formulation (FMA = 2): a sweep is 8K + 12 per individual (two K-term normalisers, ONE reciprocal of their
-                  # product with its third-order step, 2K accumulations per parent), the gamma step 89K + 25 (normalisers 4K,
-                  # update 7K -- 10K in the full-size K <= 8 instantiation, which keeps the literal form --, exp(psi) 78K).
-                  literal_step = k <= 8 and sc > 15 * 65536
-                  hand = ppu * sc * (8.0 * k + 12.0) + sc * ((92.0 if literal_step else 89.0) * k + 25.0)
-                  flops = rec.get("fp64_flops_per_update")
-                  flops_src = ("hand count of the kernel's formulation (" + (pmc_stale[0] or "no counter record for this N, K in "
-                               "profiles/pass_kernel_pmc.json") + ")")
-                  if flops:
-                      flops_src = "SQ_INSTS_VALU_*_F64 counters of a profiled launch: " + ", ".join(rec.get("flops_source_files", []))
-                  else:
-                      flops = hand
-                  tflops = flops * upd / launch_s / 1e12
-                  # (2) memory: what the kernel itself must move per update -- gamma and c_n, read and written, of the items
-                  # whose gamma is not kept in LDS, one 2-bit column -- and what the counters saw
-                  vec, items, n_lds = resident_geometry(k)
-                  moved = (16.0 * sc * k + 8.0 * sc) * (items - n_lds) / items + sc / 4.0
-                  traffic = rec.get("hbm_bytes_per_update")
-                  # (3) the reference's dataflow (SURVEY 8d): per update one first pass 32NK + 8N + N/2 and passes - 1 plain
-                  # passes 8NK + N/4 -- what this kernel would have to move if the weights did not stay in registers
-                  alg_bytes = (nsteps * first_bytes + max(0, ran - nsteps) * pass_bytes) / prs["pass_launches"]
-                  # (4) latency: the in-launch exchanges, during which the vector ALU idles (in-kernel timers of the
-                  # diagnostic build -DTSAMD_SCHED_TIME, recorded with the counters)
-                  xus = rec.get("exchange_us_per_update")
-                  roofline = {
-                      "bound": "fp64_valu",
-                      "kernel": (f"ts_schedule<{k}> (one launch = {upd:.0f} SNP updates: the gamma step and all {ppu:.3g} passes of every "
-                                 "SNP; weights in registers from the first SNP to the last; partial rows exchanged inside the launch)"),
-                      "achieved": round(tflops, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                      "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4),
-                      "traffic": None if traffic is None else traffic * upd,
-                      "flops_per_update": flops, "flops_per_update_hand_count": hand, "flops_source": flops_src,
-                      "avg_launch_us": round(launch_s * 1e6, 1), "launches_timed": prs["pass_launches"], "updates_per_launch": upd,
-                      "per_update_us": round(launch_s * 1e6 / upd, 3), "passes_per_update": round(ppu, 3),
-                      "bound_note": ("fp64 vector issue: the kernel runs one wave per SIMD (a thread owns the whole register file), where "
-                                     "tools/fma_probe reaches 62.5 of the 78.6 TFLOP/s; the rest of the distance is the exchange latency "
-                                     "(`latency`) and instructions that are not flops (register moves between the AGPR-resident weights "
-                                     "and the ALU, code decode): every vector instruction costs the lone wave 4.3-4.7 cycles, "
-                                     "tools/ubench/op_cost.hip.  HBM is far from binding (`hbm`)."),
-                      "hbm": {
-                          "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                          "achieved": None if traffic is None else round(traffic * upd / launch_s / 1e9, 1),
-                          "frac": None if traffic is None else round(traffic * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),
-                          "traffic_bytes_per_update": traffic,
-                          "moved_bytes_per_update": moved, "moved_GBps": round(moved * upd / launch_s / 1e9, 1),
-                          "moved_frac": round(moved * upd / launch_s / 1e9 / HBM_PEAK_GBS, 4),
-                          "note": ("achieved / frac: FETCH_SIZE x 2 + WRITE_SIZE of a profiled launch (profiles/pass_kernel_pmc.json) over "
-                                   "this run's launch time; moved_*: the bytes the kernel must move by construction (streamed gamma "
-                                   "read + write, c_n, one 2-bit column)"),
-                      },
-                      "algorithmic_bandwidth_equiv": {
-                          "bytes_per_update": alg_bytes / upd, "GBps": round(alg_bytes / launch_s / 1e9, 1),
-                          "note": ("SURVEY 8(d) bytes of the reference's dataflow (every pass re-reads the N x K weights) over this kernel's "
-                                   "time: a speed-up figure against a memory-bound implementation, not a fraction of any peak -- the "
-                                   "kernel does not move these bytes"),
-                      },
-                      "latency": {
-                          "exchanges_per_update": round(ppu, 3),
-                          "exchange_us_per_update": xus,
-                          "frac_of_update": None if xus is None else round(xus / (launch_s * 1e6 / upd), 4),
-                          "source": rec.get("exchange_source", "no in-kernel timer record for this N, K"),
-                      },
-                      "launch_per_snp": per_snp,
-                      "first_pass": None if per_snp is None else per_snp["first_pass"],
-                      "probe_read_us": None if read_us is None else round(read_us, 3),
-                  }
-              # A shard above ts_schedule's register capacity runs the same one-launch structure as ts_hybrid: part of the
-              # weights in registers + LDS, the rest re-read from memory every pass, all of gamma streamed -- that kernel is
-              # bound by memory, and priced so: the bytes it must move by construction over the launch time against the HBM peak.
-              try:
-                  geo = eng.schedule_geometry()
-              except Exception:  # noqa: BLE001
-                  geo = None
-              if roofline is not None and roofline.get("bound") == "fp64_valu" and geo and geo["indivs_per_thread"] > resident_geometry(k)[1]:
-                  on_chip = min(sc, geo["workgroups"] * 256 * geo["on_chip_per_thread"])
-                  streamed = sc - on_chip
-                  ppu_ = roofline["passes_per_update"]
-                  upd_ = roofline["updates_per_launch"]
-                  launch_s_ = roofline["avg_launch_us"] * 1e-6
-                  moved_h = ppu_ * streamed * 8.0 * k + sc * (16.0 * k + 8.0) + streamed * 16.0 * k + (ppu_ + 1.0) * sc / 4.0
-                  kernel_h = (f"ts_hybrid<{k}> (one launch = {upd_:.0f} SNP updates; of a thread's {geo['indivs_per_thread']} individuals "
-                              f"{geo['on_chip_per_thread']} keep their weights in registers + LDS for the whole launch, the weights of the "
-                              "others are re-read every pass; gamma and c_n of all stream through the gamma step)")
-                  hbm_h = {"bound": "hbm", "achieved": round(moved_h * upd_ / launch_s_ / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(moved_h * upd_ / launch_s_ / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_update": moved_h,
-                           "algorithmic_bytes_note": ("passes x streamed individuals x 8K (weights re-read) + N (16K + 8) (gamma, c_n read and "
-                                                      "written) + streamed x 16K (their weights read and written by the gamma step) + "
-                                                      "(passes + 1) N / 4 (columns)"),
-                           "streamed_individuals": int(streamed), "on_chip_individuals": int(on_chip)}
-                  if streamed > 0:   # memory binds: the streamed weights and the gamma step's streams
-                      fp64 = {key: roofline[key] for key in ("achieved", "peak", "unit", "frac", "flops_per_update", "flops_per_update_hand_count",
-                                                             "flops_source")}
-                      fp64["bound"] = "fp64_valu"
-                      roofline.update(hbm_h)
-                      roofline.update({
-                          "kernel": kernel_h, "fp64_valu": fp64,
-                          "bound_note": ("memory: the streamed weights (Infinity Cache / HBM) and the gamma step's streams; the exchanges and "
-                                         "epilogues (`latency`) run with the memory system idle"),
-                      })
-                  else:              # everything on chip: like ts_schedule, with all of gamma streamed through the gamma step
-                      roofline["kernel"] = kernel_h
-                      roofline["hbm"] = hbm_h
-                  roofline["traffic"] = None if not rec.get("hbm_bytes_per_update") else rec["hbm_bytes_per_update"] * upd_
-          else:
-              roofline = per_snp
-          if roofline is not None:
-              roofline["counter_records"] = pmc_stale[0] or "profiles/pass_kernel_pmc.json matches the kernel sources of this tree (or holds no record for this shape)"
-      except Exception as exc:  # noqa: BLE001 -- the measured value must still be reported (e.g. a peer timed out in a profiling leg)
-        roofline = None
-        print(f"[bench] roofline legs failed, reported without them: {exc}", file=sys.stderr, flush=True)
-
-    # third denominator (SURVEY 8d): what a plain device-to-device copy reaches on this box,
-    # with the benchmark's data still resident (read + write bytes over the copy time)
-    if roofline is not None and world == 1:
-        try:
-            dev = torch.device("cuda", local_rank)
-            src = torch.empty(1 << 27, dtype=torch.float64, device=dev)  # 1 GiB
-            dst = torch.empty_like(src)
-            src.zero_()
-            for _ in range(2):
-                dst.copy_(src)
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            for _ in range(10):
-                dst.copy_(src)
-            ev1.record()
-            torch.cuda.synchronize(dev)
-            roofline["device_copy_GBps"] = round(10 * 2 * src.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
-            del src, dst
-        except Exception as exc:  # noqa: BLE001 -- an extra, never fatal
-            roofline["device_copy_GBps"] = None
-            print(f"[bench] device copy probe skipped: {exc}", file=sys.stderr, flush=True)
-
-    # ---- the validation block (compute_likelihood, src/snpsamplinge.cc:461-544) at this configuration: the reference's sample
-    # (floor(0.005 L) locations x N/100 held-out individuals, src/snpsamplinge.cc:196-224) registered through tsamd_set_heldout,
-    # reports through tsamd_heldout_eval -- batched (ts_holblock) and, for comparison, entry by entry (TSAMD_HOLBLOCK=0).
-    # Not part of `value`: a report runs once per -rfreq training updates.
-    validation = None
-    nval = min(5000, l // 200) if args.validation_locs < 0 else min(args.validation_locs, l - 8)
-    if rank == 0 and world == 1 and nval >= 2 and not args.no_profile:
-        try:
-            try:
-                eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
-            except ts.TsamdError:
-                pass
-            vrng = np.random.default_rng(args.seed + 77)
-            vlocs = np.sort(8 + vrng.choice(l - 8, size=nval, replace=False)).astype(np.uint32)
-            per_loc = n // 10 if n < 2000 else n // 100
-            tv0 = time.perf_counter()
-            for loc in vlocs:
-                eng.set_heldout(int(loc), np.sort(vrng.choice(n, size=per_loc, replace=False)).astype(np.uint32))
-            t_set = time.perf_counter() - tv0
-            train = vrng.integers(0, l, size=64).astype(np.uint32)
-
-            def report():
-                eng.run_schedule(train)        # (a report follows training: its first entry applies the pending gamma step)
-                eng.synchronize()
-                tq = time.perf_counter()
-                sq, cq, _, _ = eng.heldout_eval(vlocs, run_updates=True)
-                return time.perf_counter() - tq, sq, cq
-
-            report()
-            batched = sorted(report() for _ in range(3))[1]
-            info = eng.holblock_info()
-            os.environ["TSAMD_HOLBLOCK"] = "0"
-            try:
-                single = report()
-            finally:
-                del os.environ["TSAMD_HOLBLOCK"]
-            tq = time.perf_counter()
-            eng.heldout_eval(vlocs, run_updates=False)
-            t_eval = time.perf_counter() - tq
-            validation = {
-                "locations": int(nval), "heldout_per_location": int(per_loc), "heldout_entries": int(batched[2]),
-                "kernel": (f"ts_holblock<{k}>: {info['batch']} locations per sweep group and exchange" if info["batch"] else
-                           "entry by entry (the context does not run the batched validation kernel)"),
-                "seconds_per_report": round(batched[0], 4), "us_per_location": round(batched[0] / nval * 1e6, 2),
-                "entry_by_entry_seconds_per_report": round(single[0], 4),
-                "entry_by_entry_us_per_location": round(single[0] / nval * 1e6, 2),
-                "evaluation_only_seconds": round(t_eval, 4),
-                "mean_loglik": round(batched[1] / max(1, batched[2]), 6),
-                "set_heldout_seconds": round(t_set, 2),
-                "note": ("one report = hol-mode updates of all validation locations (theta frozen: batched) + the held-out "
-                         "log-likelihood of all entries; wall time of tsamd_heldout_eval, median of three"),
-            }
-        except Exception as exc:  # noqa: BLE001 -- an extra, never fatal
-            print(f"[bench] validation-block leg failed, reported without it: {exc}", file=sys.stderr, flush=True)
-
-    # ---- CPU baseline: the oracle ("port") on the host cores, bounded sample; then the GPU ----
-    # ---- repeats exactly those updates from the same start and the two states are compared ----
-    cpu, parity = None, None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0 and oracle_ok:
-        import oracle_py as op
-
-        ls = 8  # sample columns; per-update cost does not depend on L
-        g0 = gamma_init()
-        sample = np.stack([eng.download_bed(int(j)) for j in range(ls)])
-
-        def run_oracle(threads, budget, max_updates):
-            orc = op.Oracle(n, ls, k, nthreads=threads, gamma_scale=float(l))
-            orc.load_bed_payload(sample)
-            orc.set_gamma(g0)
-            seq = [0]
-            orc.snp_update(0)  # untimed: the first call has no gamma step to apply
-            done, tc0 = 0, time.perf_counter()
-            while True:
-                seq.append((done + 1) % ls)
-                orc.snp_update(seq[-1])
-                done += 1
-                if time.perf_counter() - tc0 > budget or done >= max_updates:
-                    break
-            return orc, seq, done, time.perf_counter() - tc0
-
-        orc, seq, done, cdt = run_oracle(cores, args.cpu_seconds * 0.75, args.steps)
-        want = (orc.lambda_(), orc.gamma(), orc.c_indiv())
-        orc.close()
-        orc1, _, done1, cdt1 = run_oracle(1, args.cpu_seconds * 0.25, 4)
-        orc1.close()
-        cpu = {"value": round(done / cdt, 4), "unit": "SNP-minibatch updates/s", "cores": cores,
-               "kind": "port", "value_1_thread": round(done1 / cdt1, 4),
-               "sample": f"{done} updates (10 passes + gamma step each) at N={n}, K={k} on {ls} of the "
-                         f"benchmark's own columns, oracle/ts_oracle.c with {cores} OpenMP threads "
-                         f"in the reference's work partition (host shows {os.cpu_count()} CPUs, "
-                         f"{cores} usable under its affinity mask / cgroup quota); value_1_thread: "
-                         f"{done1} updates with one thread"}
-        # the same updates on the GPU, from the same state (lambda of the sample columns back to
-        # eta, gamma and c_n back to the start, no pending step), through the timed entry point -- in the mode that was
-        # timed and in every other launch mode whose kernels this line publishes timings of (roofline.launch_per_snp /
-        # first_pass)
-        eta = np.ones((k, 2))
-
-        def gpu_repeat():
-            for j in range(ls):
-                eng.set_lambda(j, eta)
-            eng.set_gamma(g0)
-            eng.set_counts(np.zeros(n, dtype=np.uint32))
-            eng.clear_pending()
-            eng.run_schedule(np.array(seq, dtype=np.uint32))
-            eng.synchronize()
-            e_lam = rel_err(eng.get_lambda(0, ls), want[0])
-            e_gam = rel_err(eng.get_gamma(), want[1])
-            cnt_eq = bool(np.array_equal(eng.get_counts(), want[2]))
-            return {"lambda_rel_err": e_lam, "gamma_rel_err": e_gam, "c_n_equal": cnt_eq,
-                    "ok": bool(e_lam < 1e-9 and e_gam < 1e-9 and cnt_eq)}
-
-        parity = gpu_repeat()
-        parity.update({"updates": len(seq), "tolerance": 1e-9, "kernels_per_snp": eng.launch_info()["kernels_per_snp"]})
-        timed_kps = eng.launch_info()["kernels_per_snp"]
-        others = {}
-        for name, m in (("launch_per_snp", ts.LAUNCH_PER_SNP), ("launch_per_pass", ts.LAUNCH_PER_PASS)):
-            try:
-                eng.set_launch_mode(m)
-            except ts.TsamdError:
-                continue                                  # the context does not qualify for it
-            if eng.launch_info()["kernels_per_snp"] != timed_kps:
-                others[name] = gpu_repeat()
-                others[name]["kernels_per_snp"] = eng.launch_info()["kernels_per_snp"]
-        if others:
-            parity["other_launch_modes"] = others
-            parity["ok"] = bool(parity["ok"] and all(o["ok"] for o in others.values()))
+    m = measure_legs(args, ts, eng, dist, rank, world, local_rank, n, l, k, sc, locs, cores, oracle_ok, gamma_init)
+    roofline, cpu, parity, validation, legs = m["roofline"], m["cpu_baseline"], m["parity"], m["validation_block"], m["legs"]
 
     if rank == 0:
         alg_update = (mean_passes + 4) * 8.0 * n * k + (mean_passes + 1) * n / 4.0 + 8.0 * n
@@ -862,6 +982,7 @@ def main():
                       "note": ("untimed priming schedule queued right ahead of the warm-up, no synchronisation in between: the "
                                "device is at its steady clocks when the timed region starts (--ramp-seconds 0 disables)")},
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_baseline": parity, "validation_block": validation,
+            "legs": legs,
         }
         print(json.dumps(out), flush=True)
     eng.close()

@@ -441,7 +441,13 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
   };
   c->block = block;
   c->first_vec = env_u32("TSAMD_FIRST_VEC", 1) == 2 ? 2 : 1;
-  geometry(p.npairs, block, env_u32("TSAMD_GRID", 256), p.chunk, c->grid);
+  // Ranks that SHARE one device (tests, rehearsals: TSAMD_DEVICE_SHARE=<ranks>): a pass kernel of the peer-to-peer sequence
+  // spins in its prologue until every rank's rows of the previous pass have arrived, so all ranks' kernels must fit the
+  // device together -- a first pass that fills every compute unit (it is register-bound: one workgroup per unit from K = 12
+  // on) would keep its peers' previous passes off the device until its bounded wait gives up (4 ranks x 250 000 individuals,
+  // K = 20: "timed out waiting for a peer (epoch 2)").  Each rank gets its share of the workgroups.  One rank per device: 1.
+  const uint32_t share = std::max<uint32_t>(1u, std::max<uint32_t>(c->device_share, env_u32("TSAMD_DEVICE_SHARE", 1)));
+  geometry(p.npairs, block, env_u32("TSAMD_GRID", share > 1u ? std::max<uint32_t>(8u, 256u / share) : 256u), p.chunk, c->grid);
   // first pass: exactly as many workgroups as are resident at once (one round; the kernel is
   // register-bound, so that is 2 per compute unit at K = 8 and 1 from K = 12 on)
   uint32_t first_target = 512;
@@ -451,6 +457,7 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
     if (nb > 0 && hipGetDeviceProperties(&prop, c->dev) == hipSuccess && prop.multiProcessorCount > 0)
       first_target = (uint32_t)prop.multiProcessorCount * (uint32_t)std::min(nb, 4);
   }
+  if (share > 1u) first_target = std::max<uint32_t>(8u, std::min<uint32_t>(first_target, 256u) / share);
   geometry(p.npad / c->first_vec, 256, env_u32("TSAMD_GRID_FIRST", first_target), p.chunk_first, c->grid_first);
 }
 
@@ -531,20 +538,24 @@ void choose_sharded_schedule(tsamd_ctx *c) {
     // the instantiations tsamd_hyb.hip carries)
     hybrid = attempt == 1;
     if (hybrid && (cfg.world > 4u || env_u32("TSAMD_HYBRID", 1) == 0u || kHybridBlocksPerCu[cfg.k]() < 1)) return;
-    bool ok = true;
+    bool ok = true, too_big = false;
     for (uint32_t r = 0; r < cfg.world && ok; ++r) {
       uint32_t b = 0, cnt = 0, grid = 0, chunk = 0;
       tsamd_shard_range(cfg.n, r, cfg.world, &b, &cnt);
       const uint32_t npad_r = (cnt + 511u) / 512u * 512u;
-      ok = (hybrid ? hybrid_geometry(cfg.k, npad_r, cap, &grid, &chunk) : resident_geometry(cfg.k, npad_r, cap, &grid, &chunk)) &&
-           grid >= (uint32_t)kResGroups;
+      const bool fits = hybrid ? hybrid_geometry(cfg.k, npad_r, cap, &grid, &chunk) : resident_geometry(cfg.k, npad_r, cap, &grid, &chunk);
+      too_big = too_big || !fits;
+      ok = fits && grid >= (uint32_t)kResGroups;
       if (r == cfg.rank) {
         my_grid = grid;
         my_chunk = chunk;
       }
     }
     if (ok) break;
-    if (hybrid) return;
+    // ts_hybrid is for shards ABOVE the register capacity.  A shard too SMALL to fill 8 workgroups (up to ~1 800 individuals:
+    // not every group of every rank would post a sum) stays with one launch per pass and the peer-to-peer rows -- an
+    // untuned hybrid geometry of 16 individuals per workgroup is not what such a run should get (advisor, round 4)
+    if (hybrid || !too_big) return;
   }
   if (!alloc_res(c)) return;
   c->sched_grid = my_grid;
@@ -1446,7 +1457,9 @@ static int settle(tsamd_ctx *c) {
     // written anything -- and every rank, driven by the same calls, finds the same launch in its journal and replays the
     // same kernels.  Contexts of ONE process (tsamd_p2p_connect_local) are settled one after the other and would wait for
     // a peer's replay that has not been enqueued yet: they keep reporting TSAMD_ECOMM.)
-    if ((err & kFailIntact) != 0ull && !dirty && (c->cfg.world == 1u || (c->p2p && c->persistent && !c->peer_maps.empty())) && c->res && !c->recovering)
+    if (tag == 0xffffffffull)  // (tested first: on a sharded context the exchange branches below would report it as a peer that did not arrive)
+      rc = fail(c, TSAMD_EHIP, "internal error: ts_holblock was launched with a gamma step pending (the state is intact; the context is not usable)");
+    else if ((err & kFailIntact) != 0ull && !dirty && (c->cfg.world == 1u || (c->p2p && c->persistent && !c->peer_maps.empty())) && c->res && !c->recovering)
       rc = recover_from_failed_entry(c, err);
     else if (c->p2p && (c->persistent || (err & kFailIntact) != 0ull))
       rc = fail(c, TSAMD_ECOMM, "ts_schedule: the in-launch exchange across %u ranks timed out (tag %llu): a peer did not arrive, or "
@@ -1455,8 +1468,6 @@ static int settle(tsamd_ctx *c) {
                 c->cfg.world, tag, err, *(volatile unsigned long long *)(c->h_error + kHostDirtyWord), (int)c->persistent, c->peer_maps.size());
     else if (c->p2p)
       rc = fail(c, TSAMD_ECOMM, "peer-to-peer exchange timed out waiting for a peer (epoch %llu)", err);
-    else if (tag == 0xffffffffull)
-      rc = fail(c, TSAMD_EHIP, "internal error: ts_holblock was launched with a gamma step pending (the state is intact; the context is not usable)");
     else
       rc = fail(c, TSAMD_EHIP, "%s: the in-launch exchange timed out in the middle of a launch (tag %llu, %u workgroups): the state is void.  "
                 "TSAMD_PERSISTENT=0 selects one launch per SNP for the plain passes, TSAMD_RESIDENT=0 one launch per pass",
@@ -1531,7 +1542,7 @@ int tsamd_run_schedule(tsamd_ctx *c, const uint32_t *locs, uint32_t n, int hol_m
   c->journal.push_back(j);
   for (uint32_t i = 0; i < n; ++i) j.ent[i] = locs[i] | (hol_mode ? 0x80000000u : 0u);
   int rc = enqueue_entries(c, j.ent, n, false, &c->journal.back());
-  c->tail_step_pending = hol_mode == 0;
+  if (rc == TSAMD_OK) c->tail_step_pending = hol_mode == 0;  // (what was actually enqueued: a failed call leaves the flag as it was)
   if (rc == TSAMD_OK && c->p2p) {
     hipEvent_t ev = nullptr;
     if (!c->event_free.empty()) {

@@ -158,6 +158,10 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
       lam_old = p.lam[(size_t)vloc * J + vj];
       eb_used = p.eb[(size_t)vloc * J + vj];
       s_eb[vb][vj] = eb_used;
+    } else if (tid < JX) {
+      // a partial batch: the rows of the locations it does not have are swept with the others of their sub-batch (their results
+      // are never read) -- on finite values, not on whatever the shared array held (advisor, round 4)
+      s_eb[vb][vj] = 1.0;
     }
     // the batch's columns, BA at a time: every thread packs its items' codes (an item it does not own: missing)
 #pragma unroll 1

@@ -1248,9 +1248,17 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
             gx[k] += rho * (p.alpha + p.gamma_scale * e - gx[k]);
           }
         }
+#ifndef TSAMD_EXP_LATE_STORE
         if constexpr (KT <= 8) gamma_to_w<KT>(gx, wx); else gamma_to_w_lean<KT>(gx, wx);
+#endif
         cn = ok ? cn + 1u : cn;
       };
+#if defined(TSAMD_EXP_LATE_STORE) || defined(TSAMD_EXP_BURST_STORE)
+      CT ckeep[kItems];
+#endif
+#ifdef TSAMD_EXP_BURST_STORE
+      WT gkeep[kItems][KT];
+#endif
       constexpr int kFirstStreamed = sched_next_streamed(-1, kLds, kItems);
       if (kFirstStreamed < kItems) load_gamma(item_or_last((uint32_t)kFirstStreamed), gs, cs);
 #pragma unroll
@@ -1315,7 +1323,47 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         if (is_lds(t)) {
           put_lgamma(t, gv, cv);
         }
-#ifndef TSAMD_EXP_NOGSTORE  // (experiment, WRONG RESULTS: the gamma step without its stores)
+#ifdef TSAMD_EXP_LATE_STORE
+        else {
+          ckeep[t] = cv;
+        }
+        put_item(t, gv);  // (the new gamma in the place of the old weights until the second loop)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // second loop: the new weights; a streamed item's gamma / c_n leave for memory here, where nobody waits on the vector
+      // memory counter behind them (in the first loop every streamed item's loads stood behind its predecessor's stores)
+#pragma unroll
+      for (int t = 0; t < kItems; ++t) {
+        if (PARTIAL && (uint32_t)t >= cnt_wg) continue;
+        fresh();
+        WT gv[KT], wcur[KT];
+        get_item(t, gv);
+        if (!is_lds(t) && (uint32_t)t < cnt) {
+          const uint32_t i = item_or_last((uint32_t)t);
+#pragma unroll
+          for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = gv[k];
+          reinterpret_cast<CT *>(p.cnt)[i] = ckeep[t];
+        }
+        if constexpr (KT <= 8) gamma_to_w<KT>(gv, wcur); else gamma_to_w_lean<KT>(gv, wcur);
+        put_item(t, wcur);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      w_dirty = true;
+#else
+#if defined(TSAMD_EXP_BURST_STORE)  // (experiment: the streamed items' new gamma / c_n leave in one burst after the item loop)
+        else {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) gkeep[t][k] = gv[k];
+          ckeep[t] = cv;
+        }
+#elif defined(TSAMD_EXP_STORE_SAME)  // (experiment, WRONG RESULTS: every streamed item's stores land on the thread's FIRST item's lines)
+        else if (mine) {
+          const uint32_t i_same = item_or_last(0u);
+#pragma unroll
+          for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i_same] = gv[k];
+          reinterpret_cast<CT *>(p.cnt)[i_same] = cv;
+        }
+#elif !defined(TSAMD_EXP_NOGSTORE)  // (experiment, WRONG RESULTS: the gamma step without its stores)
         else if (mine) {
 #pragma unroll
           for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = gv[k];
@@ -1325,7 +1373,25 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         put_item(t, wcur);
         __builtin_amdgcn_sched_barrier(0);
       }
+#ifdef TSAMD_EXP_WBL2  // (experiment: the last wave asks the L2 to write its dirty lines back now, while the sweeps run from registers)
+      if ((tid >> 6) == 3u) asm volatile("buffer_wbl2 sc1" ::: "memory");
+#endif
+#ifdef TSAMD_EXP_BURST_STORE
+#pragma unroll
+      for (int t = 0; t < kItems; ++t) {
+        if (PARTIAL && (uint32_t)t >= cnt_wg) continue;
+        if (!is_lds(t) && (uint32_t)t < cnt) {
+          fresh();
+          const uint32_t i = item_or_last((uint32_t)t);
+#pragma unroll
+          for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = gkeep[t][k];
+          reinterpret_cast<CT *>(p.cnt)[i] = ckeep[t];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       w_dirty = true;
+#endif
     }
     TSAMD_TK(tk_gamma);
     // ---- first pass of the new SNP, from the resident weights like every later one --------------------

@@ -66,6 +66,8 @@ def test_bench_json_contract():
     assert vb["locations"] == 5 and vb["heldout_per_location"] == 300 and vb["kernel"].startswith("ts_holblock<8>: 16 locations")
     assert vb["seconds_per_report"] > 0 and vb["entry_by_entry_seconds_per_report"] > 0 and vb["evaluation_only_seconds"] >= 0
     assert 0 < vb["heldout_entries"] <= 5 * 300 and vb["mean_loglik"] < 0
+    assert all(v == "ok" for v in d["legs"].values()), d["legs"]              # every secondary leg ran (each in its own try)
+    assert {"roofline_timed_kernel", "roofline_other_launch_modes", "cpu_baseline", "parity_vs_cpu_baseline", "validation_block"} <= set(d["legs"])
 
 
 def test_bench_short_run_matches_long_run():
@@ -80,3 +82,51 @@ def test_bench_short_run_matches_long_run():
         assert r.returncode == 0, r.stderr[-3000:]
         vals[steps] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["value"]
     assert vals[20] > 0.75 * vals[600], vals
+
+
+def test_bench_two_ranks_json_contract():
+    """`bench.py --gpus 2` launched exactly as the driver launches it (torch.distributed.run, one process per rank), both
+    ranks on device 0 (TSAMD_BENCH_DEVICE=0: a functional rehearsal, the rate means nothing): the line for N > 1 is
+    complete -- the timed kernel's roofline from the timed mode alone, cpu_baseline and parity_vs_cpu_baseline from rank 0
+    with the shards' states gathered, the validation block summed over the ranks, every leg's verdict, and what RCCL said
+    when it refused two ranks on one device."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, TSAMD_BENCH_DEVICE="0", GPU_MAX_HW_QUEUES="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TSAMD_LIB", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--individuals", "60000", "--pops", "8",
+                        "--snps", "2000", "--steps", "40", "--warmup", "10", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 10 and d["scaling"] == "strong" and d["dtype"] == "f64"
+    assert d["unit"] == "updates/s" and d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-3
+    st = d["config"]["exchange_selftest"]
+    assert d["config"]["exchange"] == st["chosen"] and st["valid"][st["chosen"]] is True
+    assert st["valid"].get("p2p") is True and st["valid"].get("p2p_schedule") is True      # both peer-to-peer forms match the oracle
+    assert st["rel_err_vs_oracle"]["p2p_schedule"] < 1e-9
+    if not st["valid"].get("rccl"):                                 # (two ranks on one device: RCCL refuses -- its words are in the line)
+        assert isinstance(st.get("rccl_error"), str) and st["rccl_error"]
+    legs = d["legs"]
+    assert all(v == "ok" for v in legs.values()), legs
+    rf = d["roofline"]                                              # the timed kernel, timed in the timed mode
+    assert rf is not None and rf["avg_launch_us"] > 0 and 0.0 < rf["frac"] < 1.0
+    if d["config"]["exchange"].startswith("p2p_schedule"):
+        assert "ts_schedule<8>" in rf["kernel"] and rf["bound"] == "fp64_valu" and rf["launches_timed"] == 1 and rf["updates_per_launch"] == 40
+        assert rf["launch_per_snp"] is None                         # (no mode switch on a sharded context)
+    else:
+        assert rf["bound"] == "hbm" and "ts_pass<8" in rf["kernel"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    pv = d["parity_vs_cpu_baseline"]
+    assert pv["ok"] and pv["c_n_equal"] and pv["lambda_rel_err"] < 1e-9 and pv["gamma_rel_err"] < 1e-9
+    vb = d["validation_block"]
+    assert vb["locations"] == 10 and vb["heldout_per_location"] == 600 and 0 < vb["heldout_entries"] <= 6000 and vb["mean_loglik"] < 0
+    assert sum(d["inner_passes_histogram"].values()) == 40

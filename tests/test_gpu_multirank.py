@@ -87,10 +87,27 @@ def _assert_ranks_match(res, orc, its):
         assert np.array_equal(r["lam"], res[0]["lam"])
 
 
-@pytest.mark.parametrize("world,n,k", [(2, 3000, 6), (4, 5003, 8), (3, 1000, 3), (2, 4000, 20), (2, 2500, 40), (8, 9001, 8)])
-def test_p2p_sharded_matches_oracle(tmp_path, world, n, k):
+@pytest.mark.parametrize("world,n,k,kps", [(2, 3000, 6, 10), (4, 5003, 8, 10), (3, 1000, 3, 10), (2, 4000, 20, 0), (2, 2500, 40, 10), (8, 9001, 8, 10)])
+def test_p2p_sharded_matches_oracle(tmp_path, world, n, k, kps):
+    """Small shards over the peer-to-peer exchange.  kps pins the kernel sequence each case means to exercise (asserted in
+    the worker): shards that fill fewer than 8 workgroups -- and K = 40, above the specialised kernels -- run ONE LAUNCH PER
+    PASS with the rows pushed to every rank (10 kernels per SNP); (2, 4000, 20) fills 8 workgroups per rank and runs
+    ts_schedule (0).  A small shard must never be handed to ts_hybrid, which is for shards ABOVE the register capacity."""
     l, seed, nsnp = 32, 91, 40
-    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp)
+    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp, extra_env={"TS_EXPECT_KPS": str(kps)})
+    orc, its = _oracle_run(n, l, k, seed, nsnp)
+    _assert_ranks_match(res, orc, its)
+    assert all(int(r["kps"]) == kps for r in res)
+
+
+def test_p2p_launch_per_pass_with_large_shards_on_a_shared_device(tmp_path):
+    """4 ranks x 100 000 individuals, K = 20, one launch per pass -- the sequence a sharded recovery replays through.  A
+    first pass at K = 20 is register-bound (one workgroup per compute unit); with all ranks on ONE device each rank's
+    first pass used to fill it and keep its peers' previous passes off the device until its bounded wait gave up
+    ("timed out waiting for a peer (epoch 2)", round 4's 4-rank rehearsal).  Ranks that share a device now get their share of
+    its workgroups (configure_launch); on a node with a GPU per rank nothing changes."""
+    world, n, l, k, seed, nsnp = 4, 400_000, 16, 20, 71, 10
+    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp, extra_env={"TS_LAUNCH_MODE": "0", "TS_EXPECT_KPS": "10"})
     orc, its = _oracle_run(n, l, k, seed, nsnp)
     _assert_ranks_match(res, orc, its)
 
