@@ -32,7 +32,9 @@ def kernel_sources_sha():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("tsamd_device.h", "tsamd_kernels.h", "tsamd_resident_kernels.h", "tsamd_holblock_kernels.h", "tsamd_hybrid_kernels.h"):
+    # (the device headers AND the units that pick kernels and launch geometries: csrc/tsamd.hip and the per-K instantiation files)
+    for name in ("tsamd_device.h", "tsamd_kernels.h", "tsamd_resident_kernels.h", "tsamd_holblock_kernels.h", "tsamd_hybrid_kernels.h",
+                 "tsamd.hip", "tsamd_inst.hip", "tsamd_sched.hip", "tsamd_hol.hip", "tsamd_hyb.hip"):
         h.update(open(os.path.join(CSRC, name), "rb").read())
     return h.hexdigest()[:16]
 
@@ -65,11 +67,39 @@ def _units():
     return units
 
 
+_DEPS = {}
+
+
+def _deps(src):
+    """src and the project headers it includes, transitively (#include "..." lines): a change to the hybrid kernel's header
+    rebuilds the hybrid units and tsamd.hip, not all 129 units"""
+    if src in _DEPS:
+        return _DEPS[src]
+    seen, todo = {src}, [src]
+    while todo:
+        f = todo.pop()
+        try:
+            text = open(f).read()
+        except OSError:
+            continue
+        for line in text.splitlines():
+            line = line.strip()
+            if line.startswith('#include "'):
+                name = line.split('"')[1]
+                for d in (CSRC, os.path.join(ROOT, "include")):
+                    cand = os.path.join(d, name)
+                    if os.path.exists(cand) and cand not in seen:
+                        seen.add(cand)
+                        todo.append(cand)
+    _DEPS[src] = sorted(seen)
+    return _DEPS[src]
+
+
 def _stale(obj, src):
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
-    return any(os.path.getmtime(d) > t for d in [src] + HEADERS)
+    return any(os.path.getmtime(d) > t for d in _deps(src))
 
 
 def needs_build():

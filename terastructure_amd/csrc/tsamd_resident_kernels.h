@@ -15,11 +15,16 @@
 // update_phidad / update_lambda_t (src/snpsamplinge.hh:276-300, :416-431, src/snpsamplinge.cc:742-759),
 // update_gamma / estimate_theta (:695-740), update_lambda / estimate_beta (:267-296), optimize_lambda (:320-366).
 #pragma once
+#include <type_traits>
+
 #include "tsamd_kernels.h"
 
 namespace tsamd {
 #ifndef TSAMD_NOCOL_K
 #define TSAMD_NOCOL_K 0
+#endif
+#ifndef TSAMD_LANE_EPILOGUE  // (experiments: 0 = the shared form everywhere it was; 2 = the lane form also where the per-wave form runs)
+#define TSAMD_LANE_EPILOGUE 1
 #endif
 
 // ---- geometry per K ---------------------------------------------------------------------------------------------
@@ -242,22 +247,47 @@ __device__ __forceinline__ void res_post(unsigned long long *dst, uint32_t tag, 
 struct NoOverlap {
   __device__ __forceinline__ void operator()() const {}
 };
-template <int KT, int WR, int ONE = kResOneLevelGrid, class LAY = ResLay<KT>, class OV = NoOverlap>
+// What happens to a total once a wave has it: `sink(region, cb, nvalid, lane, s)` is called by ALL lanes of the wave that
+// swept column block cb of `region`; lane 2 j' (j' < nvalid / 2) holds the total of value 16 cb + j' in s.  The default
+// stores the totals into s_tot for whoever reads them after the exchange's closing barrier; ts_schedule runs the K x 2
+// epilogue right there, on the lanes that hold the totals (LaneEpilogue below).
+struct StoreTotals {
+  double *s_tot;
+  uint32_t J;
+  __device__ __forceinline__ void operator()(uint32_t region, uint32_t cb, uint32_t nvalid, uint32_t lane, double s) const {
+    if (lane < nvalid && !(lane & 1u)) s_tot[region * J + 16u * cb + (lane >> 1)] = s;
+  }
+};
+template <int KT, int WR, int ONE = kResOneLevelGrid, class LAY = ResLay<KT>, class OV = NoOverlap, class SINK = StoreTotals>
 __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, uint32_t tag, uint32_t width, double mine, uint32_t g, uint32_t m,
                                              uint32_t grid, double *s_tot /* [2][2K] */, int *s_alive /* [4], all 1 */, uint32_t tid,
-                                             unsigned long long code, unsigned long long ticks, OV overlap = OV()) {
+                                             unsigned long long code, unsigned long long ticks, OV overlap = OV(),
+                                             SINK sink = SINK{nullptr, 0u}) {
   using L = LAY;
   constexpr uint32_t J = 2 * KT, RB = (uint32_t)res_blocks(KT), GR = L::GR;
   constexpr int kPerWave = (2 * (int)RB + 3) / 4;  // column blocks a wave sweeps at most
   constexpr bool kWideRow = J > 64u;  // a row wider than a wave (ts_holblock): ONE region, thread tid brings value tid
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   const uint32_t nblk = width * RB;
+  if constexpr (std::is_same<SINK, StoreTotals>::value) sink = StoreTotals{s_tot, J};
   if constexpr (WR == 0) {
     if (grid == 1u) {  // ONE workgroup (the smallest cohorts): its row is the total, nothing goes through memory
       const uint32_t region = kWideRow ? 0u : tid >> 6, j = kWideRow ? tid : tid & 63u;
       if (region < width && j < J) s_tot[region * J + j] = mine;
       overlap();
       __syncthreads();
+      if constexpr (!std::is_same<SINK, StoreTotals>::value && !kWideRow) {
+        // (a sink that works on the totals where a sweep leaves them: hand them over in that layout)
+#pragma unroll
+        for (int u = 0; u < kPerWave; ++u) {
+          const uint32_t q = wave + 4u * (uint32_t)u;
+          if (q < nblk) {
+            const uint32_t rg = q / RB, cb = q % RB, nvalid = min(32u, 2u * J - 32u * cb);
+            sink(rg, cb, nvalid, lane, s_tot[rg * J + min(16u * cb + ((lane & 31u) >> 1), J - 1u)]);
+          }
+        }
+        __syncthreads();
+      }
       return true;
     }
   }
@@ -316,7 +346,7 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
                                                                   p.host_error, code, ticks, lane) && alive1;
             s = res_sum<ONE / 2>(v, lane);
           }
-          if (lane < nvalid && !(lane & 1u)) s_tot[region * J + 16u * cb + (lane >> 1)] = s;
+          sink(region, cb, nvalid, lane, s);
         }
       }
       }
@@ -418,7 +448,7 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
                                                        code, ticks, lane) && alive;
         s = res_sum<1>(v1, lane);
       }
-      if (lane < nvalid && !(lane & 1u)) s_tot[region * J + 16u * cb + (lane >> 1)] = s;
+      sink(region, cb, nvalid, lane, s);
     }
   }
   }
@@ -807,8 +837,14 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
 #elif defined(TSAMD_REPL_ALL)
   constexpr bool kRepl = KT <= 8;
 #else
-  constexpr bool kRepl = PARTIAL && KT <= 8;  // (K > 8: measured neutral to 1.5 % slower -- wider rows, more lanes in the epilogue)
+  constexpr bool kRepl = PARTIAL && KT <= 8 && TSAMD_LANE_EPILOGUE < 2;  // (K > 8: measured neutral to 1.5 % slower -- wider rows, more lanes in the epilogue)
 #endif
+  // kLane (round 5): the wave that sweeps a column block of the exchange runs the K x 2 epilogue of that block's values on the
+  // lanes that hold their totals (epilogue_values_lane: value j of block cb in lane 2 (j % 16) of wave cb) and only the
+  // results -- lambda, exp(Elogbeta), |dlambda| -- go through LDS: one workgroup barrier and one LDS round trip per pass
+  // fewer than the shared form, and one exp(psi) evaluation instead of two on the critical path.  The thread that runs value
+  // ej's epilogue keeps that value's lambda / exp(Elogbeta) of the pending pass (lam_old / eb_used) in its registers.
+  constexpr bool kLane = !kRepl && TSAMD_LANE_EPILOGUE >= 1;
   __shared__ __attribute__((aligned(16))) double s_ebw[kWaves][J];
   __shared__ double s_diffw[kWaves][J];
   __shared__ double s_red[kWaves * J];
@@ -988,6 +1024,16 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   // (default form: lam_old / eb_used live in lanes < 2K of EVERY wave and are advanced by the wave's own epilogue: lambda
   // before the pending pass' epilogue, exp(Elogbeta) of the pass that runs; eb_ran = what the last executed pass used)
   double eb_ran = 0.0;
+  // the value whose epilogue this thread runs (J: none).  Shared form: thread j, value j.  Lane form: wave cb, lane 2 j' -> value
+  // 16 cb + j' (where the exchange's sweep of column block cb leaves its total).
+  auto epi_slot = [&]() -> uint32_t {
+    if constexpr (kLane) {
+      const uint32_t ln = tid & 63u, ej = 16u * (tid >> 6) + (ln >> 1);
+      return (ln & 1u) == 0u && ln < 32u && ej < J ? ej : J;
+    } else {
+      return tid < J ? tid : J;
+    }
+  };
   auto begin_pass = [&]() {
     fresh();
     iters += 1u;
@@ -995,8 +1041,9 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     if constexpr (kRepl) {
       eb_ran = eb_used;  // (the epilogue advances eb_used; the next SNP's gamma step needs what the LAST pass used)
     } else {
-      lam_old = s_lam[tid < J ? tid : 0u];
-      eb_used = s_eb[tid < J ? tid : 0u];
+      const uint32_t ej = epi_slot();
+      lam_old = s_lam[ej < J ? ej : 0u];
+      eb_used = s_eb[ej < J ? ej : 0u];
     }
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
@@ -1060,10 +1107,8 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       for (int wv = 1; wv < kWaves; ++wv) mine += s_red[wv * J + tid];
     }
     if (defer) {  // the SNP's last pass under the cap: its row and its epilogue's inputs wait for the next exchange
-      if (tid < J) {
-        s_drow[tid] = mine;
-        s_dlam[tid] = lam_old;
-      }
+      if (tid < J) s_drow[tid] = mine;
+      if (const uint32_t ej = epi_slot(); ej < J) s_dlam[ej] = lam_old;
       complete = true;
       return true;  // (the caller's end-of-SNP barrier orders these stores)
     }
@@ -1079,32 +1124,36 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     }
     xcount += 1u;
     const uint32_t tag = xseq0 + xcount;
-#ifdef TSAMD_EXP_L2PF  // (experiment: while the workgroup waits in exchange e of a SNP, touch the gamma / c_n lines of its e-th streamed item)
-    uint32_t pf_dummy = 0u;
-    auto pf = [&]() {
-      const uint32_t e = iters - 1u;
-      uint32_t tsel = 0u, c = 0u;
-#pragma unroll
-      for (int t = 0; t < kItems; ++t)
-        if (!is_lds(t)) {
-          tsel = c == e ? (uint32_t)t : tsel;
-          c += 1u;
+    if constexpr (kLane) {
+      // the epilogue of a column block's values, run by the wave that swept it, on the lanes that hold the totals; region 1 =
+      // the deferred last pass of the previous SNP (workgroup 0 only: its inputs wait in s_sb / s_dlam)
+      auto sink = [&](uint32_t region, uint32_t cb, uint32_t nvalid, uint32_t ln, double sv) {
+        const uint32_t j = 16u * cb + ((ln & 31u) >> 1);
+        const bool has = ln < nvalid && !(ln & 1u);
+        double nw, ebn, df;
+        if (region == 0u) {
+          epilogue_values_lane(p, ln, sv, eb_used, lam_old, nw, ebn, df);
+          if (has) {
+            s_lam[j] = nw;
+            s_eb[j] = ebn;
+            s_diff[j] = df;
+          }
+        } else {
+          const uint32_t jj = has ? j : 0u;
+          epilogue_values_lane(p, ln, sv, s_sb[jj], s_dlam[jj], nw, ebn, df);
+          if (has) {
+            s_dolam[j] = nw;
+            s_doeb[j] = ebn;
+          }
         }
-      if (e < (uint32_t)(kItems - kLds)) {
-        const uint32_t i = item_or_last(tsel);
-#pragma unroll
-        for (int k = 0; k < KT; ++k) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(p.gam + (size_t)k * np + i) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(p.cnt + i) : "memory");
-      }
-    };
-    const bool xok = res_exchange<KT, WR, kResOneLevelGrid, ResLay<KT>, decltype(pf)>(xb, p, tag, width, mine, g, m, gridDim.x, s_tot, s_alive, tid,
-                                                                                   fail_code(tag, false, par, serial), kResWaitTicks, pf);
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf_dummy) : "memory");
-    if (!xok) return false;
-#else
-    if (!res_exchange<KT, WR>(xb, p, tag, width, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial), kResWaitTicks))
-      return false;
-#endif
+      };
+      if (!res_exchange<KT, WR, kResOneLevelGrid, ResLay<KT>, NoOverlap, decltype(sink)>(xb, p, tag, width, mine, g, m, gridDim.x, s_tot, s_alive, tid,
+                                                                                       fail_code(tag, false, par, serial), kResWaitTicks, NoOverlap(), sink))
+        return false;
+    } else {
+      if (!res_exchange<KT, WR>(xb, p, tag, width, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial), kResWaitTicks))
+        return false;
+    }
 #ifdef TSAMD_SCHED_TIME
     const unsigned long long te0 = wall_clock64();
     tk_xchg += te0 - tx0;
@@ -1134,10 +1183,12 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       }
       complete = epilogue_complete(p, iters, J, s_diffw[wave]);
     } else {
-    if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);
-    if (deferred && blockIdx.x == 0 && tid >= 64u && tid < 64u + J)  // the previous SNP's final epilogue, beside the new pass' one
-      epilogue_values_at(p, tid - 64u, s_tot[J + tid - 64u], s_sb[tid - 64u], s_dlam[tid - 64u], s_dolam, s_doeb, s_ddiff);
-    __syncthreads();
+    if constexpr (!kLane) {
+      if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);
+      if (deferred && blockIdx.x == 0 && tid >= 64u && tid < 64u + J)  // the previous SNP's final epilogue, beside the new pass' one
+        epilogue_values_at(p, tid - 64u, s_tot[J + tid - 64u], s_sb[tid - 64u], s_dlam[tid - 64u], s_dolam, s_doeb, s_ddiff);
+      __syncthreads();
+    }  // (lane form: the epilogues ran inside the exchange, ahead of its closing barrier)
     if (deferred) {
       if (blockIdx.x == 0) {  // publish the previous SNP (before this workgroup joins the next exchange)
         if (tid < J) {
@@ -1149,7 +1200,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       }
       deferred = false;
     }
-    complete = epilogue_complete(p, iters, J, s_diff);
+    if constexpr (KT > 8) complete = epilogue_complete_wave<J>(p, iters, s_diff, tid & 63u); else complete = epilogue_complete(p, iters, J, s_diff);
     }
 #ifdef TSAMD_SCHED_TIME
     tk_epi += wall_clock64() - te0;
@@ -1198,15 +1249,9 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       WT gs[KT];  // the streamed item in flight (requested one streamed item ahead)
       CT cs;
       auto load_gamma = [&](uint32_t i, WT (&gq)[KT], CT &cq) {
-#ifdef TSAMD_EXP_NOGLOAD  // (experiment, WRONG RESULTS: the gamma step without its loads -- what do they cost?)
-#pragma unroll
-        for (int k = 0; k < KT; ++k) gq[k] = 1.0 + 1.0e-3 * (double)(k + (int)(i & 7u));
-        cq = 5u;
-#else
 #pragma unroll
         for (int k = 0; k < KT; ++k) gq[k] = reinterpret_cast<const WT *>(p.gam + (size_t)k * np)[i];
         cq = reinterpret_cast<const CT *>(p.cnt)[i];
-#endif
       };
       // one individual: update_gamma + update_rho_indiv (src/snpsamplinge.cc:688-719) with nodekappa = 0.5 (the host
       // selects this kernel only then), then the new weights.  An unobserved genotype takes the same instructions
@@ -1248,17 +1293,9 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
             gx[k] += rho * (p.alpha + p.gamma_scale * e - gx[k]);
           }
         }
-#ifndef TSAMD_EXP_LATE_STORE
         if constexpr (KT <= 8) gamma_to_w<KT>(gx, wx); else gamma_to_w_lean<KT>(gx, wx);
-#endif
         cn = ok ? cn + 1u : cn;
       };
-#if defined(TSAMD_EXP_LATE_STORE) || defined(TSAMD_EXP_BURST_STORE)
-      CT ckeep[kItems];
-#endif
-#ifdef TSAMD_EXP_BURST_STORE
-      WT gkeep[kItems][KT];
-#endif
       constexpr int kFirstStreamed = sched_next_streamed(-1, kLds, kItems);
       if (kFirstStreamed < kItems) load_gamma(item_or_last((uint32_t)kFirstStreamed), gs, cs);
 #pragma unroll
@@ -1311,87 +1348,17 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         } else {
           gamma_one(gv, wcur, pcode, cv);
         }
-#if defined(TSAMD_EXP_PIN_ALL) || defined(TSAMD_EXP_PIN_LDS)  // (experiments: the new weights are formed inside the item loop)
-#ifdef TSAMD_EXP_PIN_LDS
-        if (is_lds(t))
-#endif
-        {
-#pragma unroll
-          for (int k = 0; k < KT; ++k) asm volatile("" : "+v"(wcur[k]));
-        }
-#endif
         if (is_lds(t)) {
           put_lgamma(t, gv, cv);
-        }
-#ifdef TSAMD_EXP_LATE_STORE
-        else {
-          ckeep[t] = cv;
-        }
-        put_item(t, gv);  // (the new gamma in the place of the old weights until the second loop)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // second loop: the new weights; a streamed item's gamma / c_n leave for memory here, where nobody waits on the vector
-      // memory counter behind them (in the first loop every streamed item's loads stood behind its predecessor's stores)
-#pragma unroll
-      for (int t = 0; t < kItems; ++t) {
-        if (PARTIAL && (uint32_t)t >= cnt_wg) continue;
-        fresh();
-        WT gv[KT], wcur[KT];
-        get_item(t, gv);
-        if (!is_lds(t) && (uint32_t)t < cnt) {
-          const uint32_t i = item_or_last((uint32_t)t);
-#pragma unroll
-          for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = gv[k];
-          reinterpret_cast<CT *>(p.cnt)[i] = ckeep[t];
-        }
-        if constexpr (KT <= 8) gamma_to_w<KT>(gv, wcur); else gamma_to_w_lean<KT>(gv, wcur);
-        put_item(t, wcur);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      w_dirty = true;
-#else
-#if defined(TSAMD_EXP_BURST_STORE)  // (experiment: the streamed items' new gamma / c_n leave in one burst after the item loop)
-        else {
-#pragma unroll
-          for (int k = 0; k < KT; ++k) gkeep[t][k] = gv[k];
-          ckeep[t] = cv;
-        }
-#elif defined(TSAMD_EXP_STORE_SAME)  // (experiment, WRONG RESULTS: every streamed item's stores land on the thread's FIRST item's lines)
-        else if (mine) {
-          const uint32_t i_same = item_or_last(0u);
-#pragma unroll
-          for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i_same] = gv[k];
-          reinterpret_cast<CT *>(p.cnt)[i_same] = cv;
-        }
-#elif !defined(TSAMD_EXP_NOGSTORE)  // (experiment, WRONG RESULTS: the gamma step without its stores)
-        else if (mine) {
+        } else if (mine) {
 #pragma unroll
           for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = gv[k];
           reinterpret_cast<CT *>(p.cnt)[i] = cv;
         }
-#endif
         put_item(t, wcur);
         __builtin_amdgcn_sched_barrier(0);
       }
-#ifdef TSAMD_EXP_WBL2  // (experiment: the last wave asks the L2 to write its dirty lines back now, while the sweeps run from registers)
-      if ((tid >> 6) == 3u) asm volatile("buffer_wbl2 sc1" ::: "memory");
-#endif
-#ifdef TSAMD_EXP_BURST_STORE
-#pragma unroll
-      for (int t = 0; t < kItems; ++t) {
-        if (PARTIAL && (uint32_t)t >= cnt_wg) continue;
-        if (!is_lds(t) && (uint32_t)t < cnt) {
-          fresh();
-          const uint32_t i = item_or_last((uint32_t)t);
-#pragma unroll
-          for (int k = 0; k < KT; ++k) reinterpret_cast<WT *>(p.gam + (size_t)k * np)[i] = gkeep[t][k];
-          reinterpret_cast<CT *>(p.cnt)[i] = ckeep[t];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       w_dirty = true;
-#endif
     }
     TSAMD_TK(tk_gamma);
     // ---- first pass of the new SNP, from the resident weights like every later one --------------------
@@ -1439,8 +1406,12 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    if constexpr (kLane) {
+      if (const uint32_t ej = epi_slot(); ej < J) s_sb[ej] = eb_used;
+    } else {
+      if (tid < J) s_sb[tid] = kRepl ? eb_ran : eb_used;
+    }
     if (tid < J) {
-      s_sb[tid] = kRepl ? eb_ran : eb_used;
       s_plam[tid] = fin_lam;  // (deferred: not the final values, and never read -- the next SNP is elsewhere)
       s_peb[tid] = fin_eb;
     }
