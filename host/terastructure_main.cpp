@@ -241,7 +241,7 @@ void usage() {
           "\t-bfile <prefix>\t same as -file <prefix>.bed\n"
           "\t-n <N>\t\t number of individuals\n"
           "\t-l <L>\t\t number of locations\n"
-          "\t-k <K>\t\t number of populations\n"
+          "\t-k <K>\t\t number of populations (this build: at most 128; the reference takes any K)\n"
           "\t-label\t\t descriptive tag for the output directory\n"
           "\t-force\t\t overwrite existing output directory\n"
           "\t-rfreq <val>\t checks for convergence and logs output every <val> iterations\n"

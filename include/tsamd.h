@@ -304,7 +304,13 @@ int tsamd_holblock_info(tsamd_ctx *ctx, uint32_t *batch, uint64_t *launches, uin
  * model, src/snpsamplinge.cc:454-457.)  A sharded context (one process per rank, tsamd_p2p_connect) does the same:
  * the entry exchange spans the ranks, so it fails on every rank with every rank's state intact, and every rank -- driven by
  * the same calls -- replays the same schedules one launch per pass; only the contexts of a tsamd_p2p_connect_local group
- * (one thread settles them one after the other) still report TSAMD_ECOMM. */
+ * (one thread settles them one after the other) still report TSAMD_ECOMM.
+ * The sharded recovery is BEST EFFORT.  The ranks agree on the entry's verdict through a second, empty exchange bounded by
+ * a third of the wait of a regular one; a rank whose last workgroup gives up right at that deadline while its peers' pass
+ * can still split the verdict (one rank replays, the others have begun to modify state and fail three exchanges later).
+ * That case is never silent: every rank then ends with TSAMD_ECOMM (the replaying rank times out waiting for peers that
+ * do not replay; a rank that went on finds the abort word and reports its state as void), and no rank continues on
+ * diverged state.  Callers of a sharded run must therefore still handle TSAMD_ECOMM from any synchronising call. */
 #define TSAMD_LAUNCH_PER_PASS 0
 #define TSAMD_LAUNCH_PER_SNP 1      /* first pass + ts_resident */
 #define TSAMD_LAUNCH_PER_SCHEDULE 2 /* ts_schedule */

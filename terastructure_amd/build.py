@@ -1,7 +1,7 @@
 """Builds libtsamd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
 The K-specialised kernels are compiled as one translation unit per K
-(csrc/tsamd_inst.hip, csrc/tsamd_sched.hip, csrc/tsamd_hol.hip and csrc/tsamd_hyb.hip with -DTSAMD_K=k), in parallel; objects are cached under
+(csrc/tsamd_inst.hip, csrc/tsamd_sched.hip, csrc/tsamd_hol.hip, csrc/tsamd_hyb.hip and csrc/tsamd_hhol.hip with -DTSAMD_K=k), in parallel; objects are cached under
 terastructure_amd/lib/obj and rebuilt when a source they include changes.
 """
 import os
@@ -34,7 +34,7 @@ def kernel_sources_sha():
     h = hashlib.sha256()
     # (the device headers AND the units that pick kernels and launch geometries: csrc/tsamd.hip and the per-K instantiation files)
     for name in ("tsamd_device.h", "tsamd_kernels.h", "tsamd_resident_kernels.h", "tsamd_holblock_kernels.h", "tsamd_hybrid_kernels.h",
-                 "tsamd.hip", "tsamd_inst.hip", "tsamd_sched.hip", "tsamd_hol.hip", "tsamd_hyb.hip"):
+                 "tsamd_hybhol_kernels.h", "tsamd.hip", "tsamd_inst.hip", "tsamd_sched.hip", "tsamd_hol.hip", "tsamd_hyb.hip", "tsamd_hhol.hip"):
         h.update(open(os.path.join(CSRC, name), "rb").read())
     return h.hexdigest()[:16]
 
@@ -63,6 +63,10 @@ def _units():
     # the above-capacity whole-schedule kernel (csrc/tsamd_hyb.hip)
     for k in range(1, SCHED_MAX_K + 1):
         units.append((os.path.join(OBJ_DIR, f"hyb_k{k}.o"), os.path.join(CSRC, "tsamd_hyb.hip"),
+                      [f"-DTSAMD_K={k}", "-mllvm", "-disable-machine-licm"]))
+    # the batched validation-mode kernel for shards above the register capacity (csrc/tsamd_hhol.hip)
+    for k in range(1, SCHED_MAX_K + 1):
+        units.append((os.path.join(OBJ_DIR, f"hhol_k{k}.o"), os.path.join(CSRC, "tsamd_hhol.hip"),
                       [f"-DTSAMD_K={k}", "-mllvm", "-disable-machine-licm"]))
     return units
 

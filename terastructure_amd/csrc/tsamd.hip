@@ -123,6 +123,7 @@ struct tsamd_ctx {
   bool can_resident = false, can_persistent = false;  // what the context qualifies for (tsamd_set_launch_mode)
   bool hybrid = false;             // the whole-schedule kernel of this context is ts_hybrid: the shard exceeds ts_schedule's register capacity
   bool can_holblock = false;       // ... and validation-mode schedules run batched (ts_holblock) while it runs ts_schedule
+  bool can_hybhol = false;         // ... or (one GPU) batched by ts_hybhol while it runs ts_hybrid
   bool tail_step_pending = false;  // the last entry enqueued was a training update: its gamma step is pending
   uint64_t holblock_launches = 0, holblock_locs = 0;
   uint32_t sched_grid = 0, sched_chunk = 0;  // launch geometry of ts_schedule (= the plain pass' on one GPU; its own when sharded)
@@ -201,13 +202,16 @@ int fail(tsamd_ctx *ctx, int code, const char *fmt, ...) {
   void launch_holblock_k##k(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t, uint32_t); \
   int holblock_blocks_per_cu_k##k();                                                                         \
   void launch_hybrid_k##k(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t, uint32_t); \
-  int hybrid_blocks_per_cu_k##k();
+  int hybrid_blocks_per_cu_k##k();                                                                           \
+  void launch_hybhol_k##k(uint32_t, uint32_t, hipStream_t, const DevParams &, uint32_t, const uint32_t *, uint32_t, uint32_t); \
+  int hybhol_blocks_per_cu_k##k();                                                                           \
+  int hybhol_batch_k##k();
 #define TSAMD_ALL_K(X)                                                                             \
   X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17)     \
   X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 }  // namespace
 namespace tsamd {
-TSAMD_ALL_K(TSAMD_DECL)  // tsamd_inst.hip, tsamd_sched.hip, tsamd_hol.hip and tsamd_hyb.hip: four translation units per K
+TSAMD_ALL_K(TSAMD_DECL)  // tsamd_inst.hip, tsamd_sched.hip, tsamd_hol.hip, tsamd_hyb.hip and tsamd_hhol.hip: five translation units per K
 }
 namespace {
 #define TSAMD_ENTRY(k) tsamd::launch_k##k,
@@ -230,6 +234,12 @@ int (*const kHolblockBlocksPerCu[kResidentMaxK + 1])() = {nullptr, TSAMD_ALL_K(T
 const ScheduleFn kHybridLaunchers[kResidentMaxK + 1] = {nullptr, TSAMD_ALL_K(TSAMD_HYB_ENTRY)};
 #define TSAMD_HYB_OCC_ENTRY(k) tsamd::hybrid_blocks_per_cu_k##k,
 int (*const kHybridBlocksPerCu[kResidentMaxK + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_HYB_OCC_ENTRY)};
+#define TSAMD_HHOL_ENTRY(k) tsamd::launch_hybhol_k##k,
+const ScheduleFn kHybholLaunchers[kResidentMaxK + 1] = {nullptr, TSAMD_ALL_K(TSAMD_HHOL_ENTRY)};
+#define TSAMD_HHOL_OCC_ENTRY(k) tsamd::hybhol_blocks_per_cu_k##k,
+int (*const kHybholBlocksPerCu[kResidentMaxK + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_HHOL_OCC_ENTRY)};
+#define TSAMD_HHOL_BATCH_ENTRY(k) tsamd::hybhol_batch_k##k,
+int (*const kHybholBatch[kResidentMaxK + 1])() = {nullptr, TSAMD_ALL_K(TSAMD_HHOL_BATCH_ENTRY)};
 
 __global__ void ts_fill_f64(double *p, size_t n, double v0, double v1) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -584,7 +594,7 @@ void activate_xchg(tsamd_ctx *c) {
     c->p.xchg_gather_leaders = (g && strcmp(g, "leaders") == 0) ? 1u : 0u;
   }
   c->split = true;
-  c->resident = c->persistent = c->can_resident = c->can_persistent = c->hybrid = c->can_holblock = false;
+  c->resident = c->persistent = c->can_resident = c->can_persistent = c->hybrid = c->can_holblock = c->can_hybhol = false;
   c->p2p = true;
   configure_launch(c, std::max<uint32_t>(16u, std::min<uint32_t>(kXchgBlocks, 512u / c->cfg.world)));
   choose_sharded_schedule(c);
@@ -845,6 +855,7 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
       c->hybrid = c->persistent = c->can_persistent = true;
     }
     c->can_holblock = c->can_persistent && !c->hybrid && cfg->world == 1u && kHolblockBlocksPerCu[cfg->k]() >= 1;  // (TSAMD_HOLBLOCK=0: read per call)
+    c->can_hybhol = c->can_persistent && c->hybrid && cfg->world == 1u && kHybholBlocksPerCu[cfg->k]() >= 1;
   }
 
   CREATE_TRY(hipMalloc((void **)&p.bed, L * p.colstride));
@@ -1271,8 +1282,8 @@ static int enqueue_entries(tsamd_ctx *c, const uint32_t *ent, uint32_t n, bool e
         HIP_TRY(c, hipEventRecord(e, c->stream));
       }
       if (jr) jr->launch_off.push_back(off);
-      (hol_block ? kHolblockLaunchers : c->hybrid ? kHybridLaunchers : kScheduleLaunchers)[c->cfg.k](c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), ent + off, len,
-                                                                     c->launch_serial++);
+      (hol_block ? (c->hybrid ? kHybholLaunchers : kHolblockLaunchers) : c->hybrid ? kHybridLaunchers : kScheduleLaunchers)[c->cfg.k](
+          c->sched_grid, c->sched_chunk, c->stream, c->p, next_parity(c), ent + off, len, c->launch_serial++);
       if (hol_block) {
         c->holblock_launches++;
         c->holblock_locs += len;
@@ -1289,7 +1300,9 @@ static int enqueue_entries(tsamd_ctx *c, const uint32_t *ent, uint32_t n, bool e
     // independent as long as they are pairwise distinct: ts_holblock runs them in batches that share one sweep of the
     // weights per sub-batch and ONE exchange per pass.  Its first entry goes through ts_schedule when a training update
     // precedes it: that is where the pending gamma step is applied (src/snpsamplinge.cc:660-668).
-    if ((ent[0] >> 31) != 0u && c->can_holblock && env_u32("TSAMD_HOLBLOCK", 1) != 0u && n >= (c->tail_step_pending ? 3u : 2u)) {
+    // (a context that runs ts_hybrid -- the shard exceeds the register capacity -- batches with ts_hybhol, which shares the
+    // streamed weights across the locations of a sub-batch as well as the exchange; its first entry goes through ts_hybrid)
+    if ((ent[0] >> 31) != 0u && (c->can_holblock || c->can_hybhol) && env_u32("TSAMD_HOLBLOCK", 1) != 0u && n >= (c->tail_step_pending ? 3u : 2u)) {
       if (c->tail_step_pending) {
         if (int rc = launch(false, 0u, 1u)) return rc;
         off = 1u;
@@ -1389,6 +1402,19 @@ static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
   }
   c->resident = c->persistent = false;
   destroy_graph(c);
+  if (c->p2p) {
+    // Ranks that SHARE this device (tests, rehearsals): the resident launch failed because something holds compute units, and
+    // the pass kernels of the replay spin in their prologues until every rank's previous pass has delivered its rows -- the
+    // ranks' kernels must fit what is LEFT of the device together, or a rank's waiting workgroups keep its peers' previous
+    // pass off it until the bounded waits give up ("the replay ... failed too": 3 ranks, K = 20 and a tenant on 200 of 256
+    // compute units, one run in two).  The replay therefore runs on an eighth of each rank's share (every rank takes this
+    // branch alike: the exchange's row layout stays consistent).  One rank per device: a pass kernel never waits for a
+    // kernel that needs the same device, nothing to do.
+    const uint32_t share = std::max<uint32_t>(1u, std::max<uint32_t>(c->device_share, env_u32("TSAMD_DEVICE_SHARE", 1)));
+    hipDeviceProp_t prop;
+    if (share > 1u && hipGetDeviceProperties(&prop, c->dev) == hipSuccess && prop.multiProcessorCount > 0)
+      configure_launch(c, std::max<uint32_t>(4u, (uint32_t)prop.multiProcessorCount / (8u * share)));
+  }
   c->q = par;  // the failed launch was to write the slot of this parity: the slot of the other one holds the state to go on from
   int rc = TSAMD_OK;
   {
@@ -1767,7 +1793,7 @@ int tsamd_comm_init(tsamd_ctx *c, const uint8_t id[TSAMD_COMM_ID_BYTES]) {
     return fail(c, TSAMD_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
   }
   c->split = true;
-  c->resident = c->persistent = c->can_resident = c->can_persistent = c->hybrid = c->can_holblock = false;
+  c->resident = c->persistent = c->can_resident = c->can_persistent = c->hybrid = c->can_holblock = c->can_hybhol = false;
   c->p.rows_from_lt = 1u;
   c->rccl_graph = env_u32("TSAMD_RCCL_GRAPH", 0) != 0u;
   destroy_graph(c);
@@ -2011,7 +2037,8 @@ int tsamd_schedule_geometry(tsamd_ctx *c, int mode, uint32_t *workgroups, uint32
 
 int tsamd_holblock_info(tsamd_ctx *c, uint32_t *batch, uint64_t *launches, uint64_t *locations) {
   CHECK_CTX(c);
-  if (batch) *batch = (c->can_holblock && c->persistent && env_u32("TSAMD_HOLBLOCK", 1) != 0u) ? (uint32_t)hol_batch((int)c->cfg.k) : 0u;
+  if (batch)
+    *batch = (c->persistent && env_u32("TSAMD_HOLBLOCK", 1) != 0u) ? (c->can_holblock ? (uint32_t)hol_batch((int)c->cfg.k) : c->can_hybhol ? (uint32_t)kHybholBatch[c->cfg.k]() : 0u) : 0u;
   if (launches) *launches = c->holblock_launches;
   if (locations) *locations = c->holblock_locs;
   return TSAMD_OK;

@@ -23,8 +23,13 @@ namespace tsamd {
 #ifndef TSAMD_NOCOL_K
 #define TSAMD_NOCOL_K 0
 #endif
-#ifndef TSAMD_LANE_EPILOGUE  // (experiments: 0 = the shared form everywhere it was; 2 = the lane form also where the per-wave form runs)
-#define TSAMD_LANE_EPILOGUE 1
+// The K x 2 epilogue on the lanes that hold the exchange's totals (round 5; 1 = where the shared form runs, 2 = also where the
+// per-wave form runs).  Measured and NOT the default: what it saves -- a workgroup barrier, an LDS round trip, one of the two
+// exp(psi) evaluations -- comes back as time inside the exchange; N = 1M, K = 8: 73.2-73.3 us per update against 72.5-73.0 for
+// the shared form; N = 125K, K = 20: 60.1-60.8 against 59.9-60.7; per-wave form at N = 100K, K = 8: 40.0 against 41.5
+// (profiles/r05_experiments.md).
+#ifndef TSAMD_LANE_EPILOGUE
+#define TSAMD_LANE_EPILOGUE 0
 #endif
 
 // ---- geometry per K ---------------------------------------------------------------------------------------------
@@ -1200,7 +1205,11 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       }
       deferred = false;
     }
+#ifdef TSAMD_SEQ_DECISION  // (experiment: the sequential sum for every K)
+    complete = epilogue_complete(p, iters, J, s_diff);
+#else
     if constexpr (KT > 8) complete = epilogue_complete_wave<J>(p, iters, s_diff, tid & 63u); else complete = epilogue_complete(p, iters, J, s_diff);
+#endif
     }
 #ifdef TSAMD_SCHED_TIME
     tk_epi += wall_clock64() - te0;

@@ -65,7 +65,7 @@ def test_hybrid_matches_the_oracle(ts, n, k):
     with eng:
         geo = eng.schedule_geometry()
         assert (geo["workgroups"], geo["indivs_per_thread"], geo["on_chip_per_thread"]) == SHAPES[(n, k)], geo
-        assert eng.launch_info()["kernels_per_snp"] == 0 and eng.holblock_info()["batch"] == 0
+        assert eng.launch_info()["kernels_per_snp"] == 0 and eng.holblock_info()["batch"] > 0   # (validation-mode schedules: ts_hybhol, tests/test_gpu_hybhol.py)
         eng.run_schedule(LOCS[:9])
         eng.run_schedule(LOCS[9:11], 1)      # validation-mode updates: no gamma step follows them
         eng.run_schedule(LOCS[11:12])

@@ -4,7 +4,7 @@
 UNIT=${UNIT:-sched}
 OUT=${OUT:-/tmp/kb}
 SRC=/root/repo/terastructure_amd/csrc/tsamd_$UNIT.hip
-LICM=""; [ "$UNIT" = sched ] && LICM="-mllvm -disable-machine-licm"
+LICM=""; [ "$UNIT" != inst ] && LICM="-mllvm -disable-machine-licm"
 for k in "$@"; do
   (mkdir -p $OUT/$UNIT$k && cd $OUT/$UNIT$k && /opt/rocm/bin/hipcc -c --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=16 \
      -I/root/repo/include -I/root/repo/terastructure_amd/csrc -DTSAMD_K=$k $LICM $EXTRA -o unit.o $SRC -save-temps=obj > log.txt 2>&1) &

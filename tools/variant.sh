@@ -22,7 +22,7 @@ if [ "$U" = sched ] || [ "$U" = all ]; then
   $CC -mllvm -disable-machine-licm -DTSAMD_K=$K "$@" -o $D/v_sched_k${K}_$NAME.o terastructure_amd/csrc/tsamd_sched.hip &
   NEW="$NEW $D/v_sched_k${K}_$NAME.o"; SKIP="$SKIP|/sched_k${K}\.o"
 fi
-if [ "$U" = hol ] || [ "$U" = hyb ]; then   # the batched validation kernel / the above-capacity kernel (csrc/tsamd_hol.hip, tsamd_hyb.hip)
+if [ "$U" = hol ] || [ "$U" = hyb ] || [ "$U" = hhol ]; then   # the batched validation kernel / the above-capacity kernel (csrc/tsamd_hol.hip, tsamd_hyb.hip)
   $CC -mllvm -disable-machine-licm -DTSAMD_K=$K "$@" -o $D/v_${U}_k${K}_$NAME.o terastructure_amd/csrc/tsamd_$U.hip &
   NEW="$NEW $D/v_${U}_k${K}_$NAME.o"; SKIP="$SKIP|/${U}_k${K}\.o"
 fi
