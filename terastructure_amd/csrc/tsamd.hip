@@ -574,6 +574,7 @@ void choose_sharded_schedule(tsamd_ctx *c) {
   c->persistent = c->can_persistent = true;
   // (validation-mode schedules run batched on every rank alike: ts_holblock<K, WR>, level 2 of its wide exchange in Xchg::res_wide)
   c->can_holblock = !hybrid && kHolblockBlocksPerCu[cfg.k]() >= 1;
+  c->can_hybhol = hybrid && kHybholBlocksPerCu[cfg.k]() >= 1;  // (... ts_hybhol<K, WR> when the ranks run ts_hybrid)
 }
 
 // Switch the kernel sequence to the exchange buffer (rows + epoch flags pushed by every

@@ -17,7 +17,8 @@
 // Every per-location sum keeps the one-location path's order (ts_hybrid: a thread's items in index order whatever holds
 // their weights, the same wave fold, the waves in order, the same member / group order in the exchange), so lambda,
 // exp(Elogbeta), pass counts and the State left behind equal ts_hybrid's for the same entries BIT FOR BIT
-// (tests/test_gpu_hybhol.py).  Launch geometry: ts_hybrid's (all workgroups, equal shares).  One GPU only.
+// (tests/test_gpu_hybhol.py).  Launch geometry: ts_hybrid's (all workgroups, equal shares).  WR > 0: one launch per rank of a
+// sharded run that runs ts_hybrid (up to 4 ranks), level 2 of the exchanges across the ranks (wide rows in Xchg::res_wide).
 // Restated reference code: as ts_holblock.
 #pragma once
 #include "tsamd_holblock_kernels.h"
@@ -26,7 +27,10 @@
 namespace tsamd {
 
 // locations per sweep: as many as the register file takes beside a useful number of register items
-constexpr int hh_sub(int k) { return k <= 4 ? 4 : k <= 20 ? 2 : 1; }
+#ifndef TSAMD_HH_SUB_MID  // (experiments: locations per sweep at K = 17 ... 21)
+#define TSAMD_HH_SUB_MID 2
+#endif
+constexpr int hh_sub(int k) { return k <= 4 ? 4 : k <= 16 ? 2 : k <= 21 ? (k <= 20 || TSAMD_HH_SUB_MID > 2 ? TSAMD_HH_SUB_MID : 1) : 1; }
 // exp(Elogbeta) of the sub-batch in vector registers for the sweep (else read as pairs from LDS at each use)
 constexpr bool hh_bs(int k) { return k <= 8; }
 // locations per exchange: a multiple of that, at most 16, rows of at most 256 values
@@ -61,7 +65,7 @@ constexpr int hh_lds_items(int k) {
   return n < room ? n : room;
 }
 
-template <int KT>
+template <int KT, int WR>
 __global__ __launch_bounds__(256, 1) void ts_hybhol(Ctl *ctl_a, const double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
                                                     const uint32_t *sched, uint32_t n_sched, ResXchg *xb, uint32_t serial, const DevParams p) {
   constexpr int BLOCK = 256, kWaves = BLOCK / 64, R = hh_reg_items(KT), Q = hh_lds_items(KT), RQ = R + Q;
@@ -121,9 +125,15 @@ __global__ __launch_bounds__(256, 1) void ts_hybhol(Ctl *ctl_a, const double *w_
   __syncthreads();
   uint32_t xcount = 1u;
   // the entry exchange: empty rows, nothing modified yet.  All workgroups resident?  (ts_hybrid's, in its layout)
-  if (!res_exchange<KT, 0>(xb, p, xseq0 + 1u, 1u, 0.0, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(xseq0 + 1u, true, par, serial),
-                           (unsigned long long)p.probe_ticks))
+  if (!res_exchange<KT, WR>(xb, p, xseq0 + 1u, 1u, 0.0, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(xseq0 + 1u, true, par, serial),
+                            WR == 0 ? (unsigned long long)p.probe_ticks : kResWaitTicks))
     return;
+  if constexpr (WR > 0) {  // (sharded: the entry's verdict is committed by a second empty exchange, as in ts_schedule)
+    xcount += 1u;
+    if (!res_exchange<KT, WR>(xb, p, xseq0 + xcount, 1u, 0.0, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(xseq0 + xcount, true, par, serial),
+                              kResWaitTicks / 3ull))
+      return;
+  }
   // the weights of the register and LDS items: loaded once, never modified (theta is frozen in validation mode)
   double buf[R][KT];
 #pragma unroll
@@ -309,8 +319,8 @@ __global__ __launch_bounds__(256, 1) void ts_hybhol(Ctl *ctl_a, const double *w_
       }
       xcount += 1u;
       const uint32_t tag = xseq0 + xcount;
-      if (!res_exchange<KX, 0, kResOneLevelGrid, Wide>(xb, p, tag, 1u, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial),
-                                                      kResWaitTicks))
+      if (!res_exchange<KX, WR, kResOneLevelGrid, Wide>(xb, p, tag, 1u, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial),
+                                                       kResWaitTicks))
         return;
       TSAMD_BK(tk_xchg);
       // the BX epilogues, one lane per (location, value); the pair sum comes from the neighbouring lane (J is even)

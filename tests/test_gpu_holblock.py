@@ -205,9 +205,9 @@ def test_block_that_cannot_be_resident_is_replayed(ts, monkeypatch):
     orc.close()
 
 
-@pytest.mark.parametrize("k", list(range(1, 33)))
+@pytest.mark.parametrize("k", [1, 3] + list(range(2, 33, 2)) + [31])   # (the even K, 1, 3 and 31 here; the odd K in tests/test_gpu_hybrid.py)
 def test_every_instantiation_of_the_block(ts, k, monkeypatch):
-    """ts_holblock<K> for EVERY K = 1 ... 32 (batches of 16 ... 4 locations, sub-batches of 4 / 2 / 1) on a shard of a few
+    """ts_holblock<K> across K = 1 ... 32 (batches of 16 ... 4 locations, sub-batches of 4 / 2 / 1) on a shard of a few
     workgroups: bit for bit the entry-by-entry path, and the oracle at 1e-9"""
     n, l = 3_000 + 97 * k, 24
     payload, g, y = data(n, l, k, 7100 + k)

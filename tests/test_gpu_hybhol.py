@@ -101,14 +101,13 @@ def check(outs, orc, its, its_block, thresh):
 
 
 # (n, k, conv_thresh): above ts_schedule's capacity; K picks the batch and the split, n the streamed items per thread
-@pytest.mark.parametrize("n,k,thresh", [(600_000, 20, None), (1_000_000, 20, 15.0), (2_000_000, 8, None), (1_200_000, 12, 30.0),
-                                        (300_000, 32, None), (1_100_000, 3, None)])
+@pytest.mark.parametrize("n,k,thresh", [(1_000_000, 20, 15.0), (2_000_000, 8, None), (1_200_000, 12, 30.0), (300_000, 32, None), (1_100_000, 3, None)])
 def test_hybrid_block_equals_entry_by_entry_bitwise_and_the_oracle(ts, n, k, thresh, monkeypatch):
     outs, orc, its, its_block = run_both(ts, monkeypatch, n, 16, k, 9100 + k, thresh)
     check(outs, orc, its, its_block, thresh)
 
 
-@pytest.mark.parametrize("k", [1, 2, 4, 5, 7, 8, 9, 10, 12, 13, 14, 16, 17, 19, 20, 21, 22, 24, 27, 31, 32])
+@pytest.mark.parametrize("k", [1, 4, 5, 8, 9, 12, 14, 16, 17, 20, 21, 24, 27, 32])
 def test_instantiations_of_the_hybrid_block_on_a_small_device(ts, k, monkeypatch):
     """ts_hybhol<K> across K (every split: 4 / 2 / 1 locations per sweep, register / LDS / streamed items) on the launch
     geometry of a device with four compute units (TSAMD_TEST_MAX_WORKGROUPS, honoured with TSAMD_FLAG_TEST_HOOKS only), so that

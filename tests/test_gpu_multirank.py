@@ -141,7 +141,6 @@ def test_p2p_small_pass_caps(tmp_path, world, max_inner):
 
 @pytest.mark.parametrize("world,n,k,thresh,max_inner", [(2, 40_000, 8, None, None), (4, 70_000, 5, None, None),
                                                         (2, 60_000, 8, 8.0, None), (3, 50_000, 3, None, 3),
-                                                        (8, 70_000, 8, None, None), (2, 300_000, 8, None, None),
                                                         (2, 40_000, 12, None, None), (2, 60_000, 20, 30.0, None),
                                                         (4, 90_000, 16, None, None), (3, 50_000, 32, None, 4),
                                                         (8, 125_000, 20, None, None)])
@@ -172,7 +171,7 @@ def test_sharded_schedule_kernel_matches_oracle(tmp_path, world, n, k, thresh, m
         assert np.array_equal(res[0]["cnt"], ref[0]["cnt"])
 
 
-@pytest.mark.parametrize("world,n,k,thresh", [(2, 60_000, 8, 8.0), (4, 90_000, 16, None), (8, 125_000, 20, None), (3, 40_000, 5, None)])
+@pytest.mark.parametrize("world,n,k,thresh", [(2, 60_000, 8, 8.0), (4, 90_000, 16, None), (3, 40_000, 5, None)])
 def test_sharded_schedule_kernel_three_levels(tmp_path, world, n, k, thresh):
     """The same with TSAMD_SCHEDULE_GATHER=leaders: only a rank's eight group leaders poll the world x 8 rows the ranks send
     each other; every other workgroup takes the total from its own group's leader (one local hop more, far less polling of
@@ -193,7 +192,33 @@ def test_sharded_schedule_kernel_three_levels(tmp_path, world, n, k, thresh):
         assert np.array_equal(res[0]["lam"], ref[0]["lam"]) and np.array_equal(res[0]["gamma"], ref[0]["gamma"])
 
 
-@pytest.mark.parametrize("world,n,k,thresh", [(2, 400_000, 20, None), (2, 600_000, 20, 15.0), (3, 1_200_000, 8, None)])
+@pytest.mark.parametrize("world,n,k,thresh", [(2, 600_000, 20, None)])
+def test_sharded_hybrid_validation_block_is_batched_and_matches(tmp_path, world, n, k, thresh):
+    """The same on shards ABOVE the register capacity (every rank runs ts_hybrid): the block runs as ts_hybhol<K, WR> launches --
+    a sub-batch of locations shares one sweep of the streamed weights, the batch one exchange across the ranks.  Against the
+    oracle, and bit for bit against the same run with TSAMD_HOLBLOCK=0 (entry by entry inside ts_hybrid)."""
+    l, seed, nsnp, nhol = 16, 83, 12, 14
+    env, over = {"TS_EXPECT_KPS": "0", "TS_EXPECT_HYBRID": "1", "TS_HOL_LOCS": str(nhol), "TS_EXPECT_HOLBLOCKS": "1"}, {}
+    if thresh is not None:
+        env["TS_CONV_THRESH"] = str(thresh)
+        over["meanchangethresh"] = thresh
+    res = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp, extra_env=env)
+    orc, its = _oracle_run(n, l, k, seed, nsnp, **over)
+    locs = np.random.default_rng(seed + 3).integers(0, l, size=nsnp)
+    its_hol = [orc.snp_update(int(x), 1) for x in range(nhol)]
+    its2 = its + its_hol + [orc.snp_update(int(x)) for x in locs[:4]]
+    for r in res:
+        assert rel_err(r["lam"], orc.lambda_()) < 1e-9 and rel_err(r["gamma"], orc.gamma()) < 1e-9
+        assert np.array_equal(r["cnt"][:, 0], orc.c_indiv()) and int(r["passes"]) == sum(its2)
+    for r in res[1:]:
+        assert np.array_equal(r["lam"], res[0]["lam"])
+    (tmp_path / "single").mkdir()
+    ref = _run_ranks(tmp_path / "single", "p2p", world, n, l, k, seed, nsnp,
+                     extra_env=dict(env, TSAMD_HOLBLOCK="0", TS_EXPECT_HOLBLOCKS="0"))
+    assert np.array_equal(res[0]["lam"], ref[0]["lam"]) and np.array_equal(res[0]["gamma"], ref[0]["gamma"])
+
+
+@pytest.mark.parametrize("world,n,k,thresh", [(2, 600_000, 20, 15.0), (3, 1_200_000, 8, None)])
 def test_sharded_hybrid_kernel_matches_oracle(tmp_path, world, n, k, thresh):
     """Shards above ts_schedule's register capacity (with the ranks sharing one GPU each gets CUs / world workgroups: 128 x 256 x 5
     individuals at K = 20 for two ranks): every rank runs ts_hybrid<K, WR> -- weights in registers + LDS, the rest streamed
@@ -211,7 +236,7 @@ def test_sharded_hybrid_kernel_matches_oracle(tmp_path, world, n, k, thresh):
     _assert_ranks_match(res, orc, its)
 
 
-@pytest.mark.parametrize("world,n,k,thresh", [(2, 40_000, 8, None), (2, 60_000, 20, 30.0), (4, 90_000, 16, None), (3, 50_000, 5, 6.0)])
+@pytest.mark.parametrize("world,n,k,thresh", [(2, 40_000, 8, None), (4, 90_000, 16, None), (3, 50_000, 5, 6.0)])
 def test_sharded_validation_block_is_batched_and_matches(tmp_path, world, n, k, thresh):
     """A validation-mode schedule on a sharded context that runs ts_schedule: every rank runs it as ts_holblock<K, WR> launches
     (wide rows exchanged across the ranks through Xchg::res_wide).  Against the oracle, and bit for bit against the same run
@@ -250,7 +275,7 @@ def test_sharded_ranks_switch_launch_modes_mid_run(tmp_path, world):
     _assert_ranks_match(res, orc, its)
 
 
-@pytest.mark.parametrize("world,n,k", [(2, 40_000, 8), (3, 30_000, 20), (2, 30_000, 20), (2, 60_000, 12)])
+@pytest.mark.parametrize("world,n,k", [(2, 40_000, 8), (3, 30_000, 20)])
 def test_sharded_schedule_that_cannot_be_resident_is_replayed_on_every_rank(tmp_path, world, n, k):
     """A tenant holds compute units when the ranks' ts_schedule launches start: the entry exchange (which spans the ranks)
     times out on every rank with every rank's state intact; every rank lowers itself to one launch per pass and replays the

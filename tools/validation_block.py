@@ -2,14 +2,16 @@
 validation sample (0.5 % of the locations, N/100 held-out individuals each: 5 000 x 10 000 entries at N = L = 1M) and
 the time of one report: a hol-mode schedule over the validation locations + one evaluation kernel
 (tsamd_heldout_eval; batched through ts_holblock, TSAMD_HOLBLOCK=0 for the entry-by-entry path).
-usage (GPU box): python tools/validation_block.py [L = 1000000]"""
+K = 20 (N = 1M: a context that runs ts_hybrid) batches through ts_hybhol.
+usage (GPU box): python tools/validation_block.py [L = 1000000] [K = 8]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import terastructure_amd as ts
 
-n, k = 1_000_000, 8
+n = 1_000_000
 l = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 rng = np.random.default_rng(3)
 e = ts.Engine(n, l, k)
 theta = rng.dirichlet(np.full(k, 0.2), size=n)
