@@ -906,6 +906,10 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     // state intact (and replays, csrc/tsamd.hip).  Bounded by a third of the entry's wait: every rank that passed the
     // first exchange posts within microseconds, and the ranks' replays must start within one peer-to-peer wait of each other.
     xcount += 1u;
+    if (p.xchg_test_delay != 0u) {  // test hook (TSAMD_TEST_XCHG_DELAY_US, contexts created with TSAMD_FLAG_TEST_HOOKS only): this rank posts its commit late
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)p.xchg_test_delay) __builtin_amdgcn_s_sleep(8);
+    }
     if (!res_exchange<KT, WR>(xb, p, xseq0 + xcount, 1u, 0.0, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(xseq0 + xcount, true, par, serial),
                               kResWaitTicks / 3ull))
       return;

@@ -58,7 +58,7 @@ def _run_ranks(tmp_path, mode, world, n, l, k, seed, nsnp, extra_env=None, ok_co
         assert p.returncode in ok_codes, f"rank {rank} failed:\n{out[-3000:]}\n" + "".join(
             f"---- rank {r} (exit code {q.returncode}) ----\n{o[-1500:]}\n" for r, (q, o) in enumerate(zip(procs, outs)) if r != rank)
     if any(p.returncode != 0 for p in procs):
-        return outs
+        return [f"[exit code {p.returncode}]\n{o}" for p, o in zip(procs, outs)]
     return [np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in range(world)]
 
 
@@ -285,6 +285,19 @@ def test_sharded_schedule_that_cannot_be_resident_is_replayed_on_every_rank(tmp_
                      extra_env={"TS_EXPECT_KPS": "0", "TS_OCCUPY": "200,4500", "TS_EXPECT_RECOVERIES": "1"})
     orc, its = _oracle_run(n, l, k, seed, nsnp)
     _assert_ranks_match(res, orc, its)
+
+
+def test_split_commit_verdict_is_never_silent(tmp_path):
+    """The residual window of the sharded recovery (include/tsamd.h: best effort): one rank posts its commit exchange 1.3 s
+    late (test hook), after its peer's bounded wait of 1 s has given up "intact".  The late rank finds the peer's row, passes,
+    starts to modify state and times out at its first real exchange; the peer replays and waits for a rank that does not.
+    EVERY rank must end with an error (TSAMD_ECOMM) -- no rank may finish as if nothing had happened."""
+    world, n, l, k, seed, nsnp = 2, 40_000, 16, 8, 97, 12
+    outs = _run_ranks(tmp_path, "p2p", world, n, l, k, seed, nsnp, ok_codes=(0, 1),
+                      extra_env={"TS_EXPECT_KPS": "0", "TS_DELAY_RANK": "1", "TS_DELAY_US": "1300000"})
+    assert isinstance(outs[0], str), "a rank finished with exit code 0 although the commit verdict was split"
+    for rank, out in enumerate(outs):
+        assert not out.startswith("[exit code 0]") and "TsamdError" in out, f"rank {rank}:\n{out[-1500:]}"
 
 
 def test_rccl_two_ranks_matches_oracle(tmp_path):
