@@ -280,9 +280,12 @@ int tsamd_schedule_geometry(tsamd_ctx *ctx, int mode, uint32_t *workgroups, uint
  * the last training update.  Results equal the entry-by-entry path bit for bit (every per-location sum keeps its order).
  * Repeated locations cut the call into blocks of distinct ones.  A sharded context (tsamd_p2p_connect) that runs
  * TSAMD_LAUNCH_PER_SCHEDULE with ts_schedule does the same on every rank alike (the batch's rows are exchanged across the
- * ranks).  batch = 0: the context runs such calls entry by entry (other launch modes, shards above the register capacity,
- * TSAMD_HOLBLOCK=0 -- read per call; the same on every rank of a sharded run).  launches / locations: ts_holblock launches so far and the
- * entries they covered.  Replaces the loop of compute_likelihood, src/snpsamplinge.cc:476-498. */
+ * ranks).  A context whose shard exceeds the register capacity (it runs ts_hybrid, one GPU or up to 4 ranks) batches the same
+ * way with ts_hybhol: a sub-batch of locations shares one sweep of the weights -- registers + LDS + the streamed rest, read once
+ * for the sub-batch -- and the batch one exchange per pass; bit for bit the entry-by-entry results as well.  batch = 0: the
+ * context runs such calls entry by entry (other launch modes, TSAMD_HOLBLOCK=0 -- read per call; the same on every rank of a
+ * sharded run).  launches / locations: ts_holblock / ts_hybhol launches so far and the entries they covered.  Replaces the loop
+ * of compute_likelihood, src/snpsamplinge.cc:476-498. */
 int tsamd_holblock_info(tsamd_ctx *ctx, uint32_t *batch, uint64_t *launches, uint64_t *locations);
 /* Selects how the context launches from now on: one kernel per pass, one resident kernel for the plain passes of
  * a SNP, or one kernel per schedule.  tsamd_create picks the highest mode the context qualifies for; this call

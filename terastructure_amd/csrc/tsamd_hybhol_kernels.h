@@ -27,10 +27,9 @@
 namespace tsamd {
 
 // locations per sweep: as many as the register file takes beside a useful number of register items
-#ifndef TSAMD_HH_SUB_MID  // (experiments: locations per sweep at K = 17 ... 21)
-#define TSAMD_HH_SUB_MID 2
-#endif
-constexpr int hh_sub(int k) { return k <= 4 ? 4 : k <= 16 ? 2 : k <= 21 ? (k <= 20 || TSAMD_HH_SUB_MID > 2 ? TSAMD_HH_SUB_MID : 1) : 1; }
+// (three at K = 20 would cut the streamed bytes per location by a third, but three locations' accumulators do not fit beside two
+// stream buffers: 39-45 spilled registers, 177 against 123 us per location -- profiles/r05_experiments.md)
+constexpr int hh_sub(int k) { return k <= 4 ? 4 : k <= 20 ? 2 : 1; }
 // exp(Elogbeta) of the sub-batch in vector registers for the sweep (else read as pairs from LDS at each use)
 constexpr bool hh_bs(int k) { return k <= 8; }
 // locations per exchange: a multiple of that, at most 16, rows of at most 256 values

@@ -19,9 +19,6 @@
 #include "tsamd_resident_kernels.h"
 
 namespace tsamd {
-#ifndef TSAMD_HY_L2PF  // (experiment: streamed items of the next pass touched into the L2 while the workgroup waits in the exchange)
-#define TSAMD_HY_L2PF 0
-#endif
 
 // items whose weights live in LDS: what 160 KB hold beside the K x 2 arrays, at most 16 (their codes share one register)
 constexpr int hy_lds_items(int k) {
@@ -235,23 +232,6 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
   double sa[KT], sbuf[KT];
   uint32_t worda = 0u, wordb = 0u;
   auto request_first = [&]() { load_streamed(0u, sa, worda); };
-#if TSAMD_HY_L2PF > 0
-  // ... and the rows of the next TSAMD_HY_L2PF streamed items are TOUCHED there as well (one dword per lane and row, loaded
-  // straight into a scratch word of LDS: no registers): they cross the fabric while the exchange has it idle, and the sweep
-  // finds them in the XCD's L2 -- the streamed items of a pass are what binds the kernel.
-  __shared__ uint32_t s_pf[64];
-  auto touch_next = [&]() {
-#pragma unroll
-    for (int s = 1; s <= TSAMD_HY_L2PF; ++s) {
-      if ((uint32_t)s >= scnt_wg) break;
-      const uint32_t i = item_or_last((uint32_t)RQ + (uint32_t)s);
-#pragma unroll
-      for (int k = 0; k < KT; ++k)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_a + (size_t)k * np + i),
-                                         (__attribute__((address_space(3))) void *)s_pf, 4, 0, 0);
-    }
-  };
-#endif
   auto sweep = [&]() {
 #pragma unroll
     for (int t = 0; t < R; ++t) {
@@ -308,12 +288,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
     const bool ahead = STREAM && iters < p.max_inner;
     auto overlap = [&]() {
       if constexpr (STREAM)
-        if (ahead) {
-          request_first();
-#if TSAMD_HY_L2PF > 0
-          touch_next();
-#endif
-        }
+        if (ahead) request_first();
     };
     if (!res_exchange<KT, WR, kResOneLevelGrid, ResLay<KT>>(xb, p, tag, 1u, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial),
                                                             kResWaitTicks, overlap))
