@@ -757,7 +757,12 @@ def measure_legs(args, ts, eng, dist, rank, world, local_rank, n, l, k, sc, locs
             tq = time.perf_counter()
             eng.heldout_eval(vlocs, run_updates=False)
             t_eval = time.perf_counter() - tq
-            return dict(batched=batched, single=single, t_eval=t_eval, t_set=t_set, per_loc=per_loc, batch=hinfo["batch"])
+            try:   # (which kernel batches: ts_holblock beside ts_schedule, ts_hybhol beside ts_hybrid -- a shard above the register capacity)
+                geo = eng.schedule_geometry()
+                hyb = geo["indivs_per_thread"] > resident_geometry(k)[1]
+            except Exception:  # noqa: BLE001 -- a label only
+                hyb = False
+            return dict(batched=batched, single=single, t_eval=t_eval, t_set=t_set, per_loc=per_loc, batch=hinfo["batch"], hybrid=hyb)
 
         v = leg("validation_block", validation_block)
         if v is not None:
@@ -768,8 +773,9 @@ def measure_legs(args, ts, eng, dist, rank, world, local_rank, n, l, k, sc, locs
                 single = (tdist.max_over_ranks(single[0], dist), single[1], single[2])
             validation = {
                 "locations": int(nval), "heldout_per_location": int(v["per_loc"]), "heldout_entries": int(batched[2]),
-                "kernel": (f"ts_holblock<{k}>: {v['batch']} locations per sweep group and exchange" if v["batch"] else
-                           "entry by entry (the context does not run the batched validation kernel)"),
+                "kernel": ((f"ts_hybhol<{k}>: {v['batch']} locations per exchange, sub-batches share one sweep of the streamed weights" if v["hybrid"]
+                            else f"ts_holblock<{k}>: {v['batch']} locations per sweep group and exchange") if v["batch"] else
+                           "entry by entry (the context does not run a batched validation kernel)"),
                 "seconds_per_report": round(batched[0], 4), "us_per_location": round(batched[0] / nval * 1e6, 2),
                 "entry_by_entry_seconds_per_report": round(single[0], 4),
                 "entry_by_entry_us_per_location": round(single[0] / nval * 1e6, 2),

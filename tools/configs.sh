@@ -13,11 +13,11 @@ timeout 600 python bench.py --individuals 125000 --snps 200000 --pops 20 --steps
 echo "### config 5's 4-GPU-class shard on one GPU: N=327680 K=20"
 timeout 600 python bench.py --individuals 327680 --snps 200000 --pops 20 --steps 2000 --warmup 200 --cpu-seconds 6 2>/dev/null | cut -c1-9000
 echo "### K=20 N=1M (config 5 on ONE GPU: ts_hybrid, L limited)"
-timeout 900 python bench.py --pops 20 --snps 200000 --steps 500 --warmup 50 --cpu-seconds 6 --validation-locs 0 2>/dev/null | cut -c1-9000
+timeout 900 python bench.py --pops 20 --snps 200000 --steps 500 --warmup 50 --cpu-seconds 6 2>/dev/null | cut -c1-9000
 echo "### K=20 N=500K (config 5's 2-GPU shard on one GPU: ts_hybrid, all on chip)"
-timeout 900 python bench.py --pops 20 --individuals 500000 --snps 200000 --steps 1000 --warmup 100 --cpu-seconds 6 --validation-locs 0 2>/dev/null | cut -c1-9000
+timeout 900 python bench.py --pops 20 --individuals 500000 --snps 200000 --steps 1000 --warmup 100 --cpu-seconds 6 2>/dev/null | cut -c1-9000
 echo "### K=8 N=2M (ts_hybrid)"
-timeout 900 python bench.py --pops 8 --individuals 2000000 --snps 100000 --steps 1000 --warmup 100 --cpu-seconds 6 --validation-locs 0 2>/dev/null | cut -c1-9000
+timeout 900 python bench.py --pops 8 --individuals 2000000 --snps 100000 --steps 1000 --warmup 100 --cpu-seconds 6 2>/dev/null | cut -c1-9000
 echo "### config 1's shape: N=200 K=3"
 timeout 600 python bench.py --individuals 200 --snps 10000 --pops 3 --steps 20000 --warmup 1000 --cpu-seconds 4 2>/dev/null | cut -c1-9000
 echo "### the same shapes, one launch per pass (TSAMD_RESIDENT=0)"
