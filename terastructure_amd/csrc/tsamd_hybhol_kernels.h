@@ -4,8 +4,8 @@
 // the workers then skip the gamma step (src/snpsamplinge.cc:660-668): theta is frozen for the whole block and distinct
 // locations are independent.  ts_holblock (tsamd_holblock_kernels.h) runs such a block BX locations at a time for shards whose
 // weights fit the register file.  A context that runs ts_hybrid -- N = 1M, K = 20 on one GPU: 160 MB of weights against a
-// 128 MB register file -- ran the block entry by entry until round 5: 290 us per location, ten sweeps each re-reading the
-// streamed half of the weights, ten exchanges.  This kernel batches it:
+// 128 MB register file -- ran the block entry by entry until round 5: 191 us per location, ten sweeps each re-reading the
+// streamed half of the weights, ten exchanges.  This kernel batches it (123 us):
 //   * nothing is modified in validation mode and no gamma is needed, so the residency split is chosen for THIS kernel:
 //     hh_reg_items(K) items of a thread in registers, hh_lds_items(K) in LDS (what the 160 KB hold beside the batch's
 //     arrays), every further item streamed from memory (Infinity Cache) through two buffers, one item ahead;
