@@ -374,4 +374,12 @@ __device__ __forceinline__ double uniform_f64(double v) {
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+// the double held by lane `lane` (a compile-time constant) of this wave -> scalar registers
+__device__ __forceinline__ double lane_f64(double v, int lane) {
+  const unsigned long long u = __double_as_longlong(v);
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)u, lane);
+  const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(u >> 32), lane);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 }  // namespace tsamd

@@ -31,6 +31,9 @@ namespace tsamd {
 #ifndef TSAMD_LANE_EPILOGUE
 #define TSAMD_LANE_EPILOGUE 0
 #endif
+#ifndef TSAMD_REPL_READLANE  // (experiment switch: 0 = the per-wave form broadcasts exp(Elogbeta) through its LDS row, as in rounds 3-4)
+#define TSAMD_REPL_READLANE 1
+#endif
 
 // ---- geometry per K ---------------------------------------------------------------------------------------------
 constexpr int kResidentMaxK = 32;
@@ -835,14 +838,18 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   // keeps lambda / exp(Elogbeta) of the pending pass in those lanes' registers: no workgroup barrier between the exchange
   // and the next sweep, nobody waits for wave 0 (-7 % per update below ~250K individuals, where an update IS its
   // exchanges and epilogues).  exp(Elogbeta) and the |dlambda| terms go through a per-wave LDS row only to be broadcast to
-  // the wave's other lanes.  K <= 8 only; the instantiation without the skip branches (full-size shards) keeps round 2's
-  // shared form -- threads < 2K, shared arrays, a barrier: with the per-wave form it no longer fits the register file.
+  // the wave's other lanes (rounds 3-4; round 5: exp(Elogbeta) goes from the lanes' registers to scalar registers with
+  // v_readlane, no LDS row).  K <= 8 only -- every instantiation since round 5; above, the shared form: threads < 2K, shared
+  // arrays, a barrier.
 #if defined(TSAMD_SHARED_EPILOGUE)  // (experiments)
   constexpr bool kRepl = false;
 #elif defined(TSAMD_REPL_ALL)
   constexpr bool kRepl = KT <= 8;
 #else
-  constexpr bool kRepl = PARTIAL && KT <= 8 && TSAMD_LANE_EPILOGUE < 2;  // (K > 8: measured neutral to 1.5 % slower -- wider rows, more lanes in the epilogue)
+  // (K > 8: measured neutral to 1.5 % slower -- wider rows, more lanes in the epilogue.  Round 5: with exp(Elogbeta) taken from the
+  // lanes' registers -- TSAMD_REPL_READLANE -- the per-wave form wins on the full-size instantiation as well: N = 1M, K = 8
+  // 72.7-73.0 against 73.6-74.0 us per update; until then it ran only below full size)
+  constexpr bool kRepl = KT <= 8 && TSAMD_LANE_EPILOGUE < 2;
 #endif
   // kLane (round 5): the wave that sweeps a column block of the exchange runs the K x 2 epilogue of that block's values on the
   // lanes that hold their totals (epilogue_values_lane: value j of block cb in lane 2 (j % 16) of wave cb) and only the
@@ -1056,7 +1063,12 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     }
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-      if constexpr (BSC) {
+      if constexpr (kRepl && BSC && TSAMD_REPL_READLANE) {
+        // per-wave form: lane j < 2K of THIS wave holds exp(Elogbeta_j) of the pass in eb_used -- taken straight from the
+        // lanes' registers (v_readlane) instead of through the wave's LDS row (a store, a wait, eight 16-byte reads)
+        b0[k] = lane_f64(eb_used, 2 * k);
+        b1[k] = lane_f64(eb_used, 2 * k + 1);
+      } else if constexpr (BSC) {
         b0[k] = uniform_f64(bsrc[2 * k]);
         b1[k] = uniform_f64(bsrc[2 * k + 1]);
       } else if constexpr (BS) {
@@ -1174,7 +1186,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         epilogue_values_reg(p, lane, s_tot[lane], eb_used, lam_old, nw, ebn, df);
         lam_old = nw;
         eb_used = ebn;
-        s_ebw[wave][lane] = ebn;
+        if constexpr (!(BSC && TSAMD_REPL_READLANE)) s_ebw[wave][lane] = ebn;
         s_diffw[wave][lane] = df;
       }
       if (deferred) {
@@ -1250,7 +1262,8 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       const uint32_t lane = tid & 63u, wave = tid >> 6;
       lam_old = s_lam[lane < J ? lane : 0u];
       eb_used = s_eb[lane < J ? lane : 0u];
-      if (lane < J) s_ebw[wave][lane] = eb_used;
+      if constexpr (!(BSC && TSAMD_REPL_READLANE))
+        if (lane < J) s_ebw[wave][lane] = eb_used;
     }
     iters = 0u;
     TSAMD_TK(tk_head);
