@@ -45,13 +45,15 @@ constexpr int hh_batch(int k) {
 #ifdef TSAMD_HH_BUDGET  // (experiments)
 constexpr int hh_budget(int) { return TSAMD_HH_BUDGET; }
 #else
-constexpr int hh_budget(int k) { return k <= 8 ? 190 : k <= 12 ? 150 : k <= 16 ? 190 : 165; }
+constexpr int hh_budget(int k) {
+  return k <= 8 ? 190 : k <= 10 ? 140 : k <= 13 ? 150 : k <= 14 ? 160 : k <= 15 ? 175 : k <= 16 ? 190 : k <= 20 ? 165 : k <= 23 ? 140 : k <= 24 ? 165 : k <= 27 ? 130 : k <= 28 ? 165 : 100;
+}
 #endif
 constexpr int hh_reg_items(int k) {
   const int ba = hh_sub(k);
   const int fixed = ba * 2 * k + (hh_bs(k) ? ba * 2 * k : 0) + 2 * k;
   int r = (hh_budget(k) - fixed) / k;
-  return r > 16 ? 16 : r < 1 ? 1 : r;
+  return r > 16 ? 16 : r < 0 ? 0 : r;  // (K >= 29: none -- the accumulators and the stream buffers take the budget; the on-chip items are the LDS ones)
 }
 // bytes of LDS the batch's arrays take (codes, rows, pairs, differences, totals, small arrays)
 constexpr int hh_batch_lds(int k) {
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybhol(Ctl *ctl_a, const double *w_
   constexpr int BA = hh_sub(KT), BX = hh_batch(KT), NSUB = BX / BA, KX = BX * KT;
   constexpr uint32_t J = 2 * KT, JX = 2 * KX;
   constexpr bool BS = hh_bs(KT);
-  static_assert(resident_vec(KT) == 1 && RQ <= 16 && R >= 1, "one individual per item; the on-chip items' codes share two registers");
+  static_assert(resident_vec(KT) == 1 && RQ <= 16 && RQ >= 1, "one individual per item; the on-chip items' codes share two registers");
   static_assert(JX <= (uint32_t)BLOCK && BX <= 16 && BX % BA == 0, "a batch's row is brought by one thread per value");
   using Wide = WideLay<KX>;
   __shared__ __attribute__((aligned(16))) double s_eb[BX][J];  // exp(Elogbeta) the running pass uses, per location of the batch
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybhol(Ctl *ctl_a, const double *w_
       return;
   }
   // the weights of the register and LDS items: loaded once, never modified (theta is frozen in validation mode)
-  double buf[R][KT];
+  double buf[R > 0 ? R : 1][KT];
 #pragma unroll
   for (int t = 0; t < R; ++t) {
 #pragma unroll
