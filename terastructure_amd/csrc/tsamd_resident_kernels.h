@@ -31,6 +31,9 @@ namespace tsamd {
 #ifndef TSAMD_LANE_EPILOGUE
 #define TSAMD_LANE_EPILOGUE 0
 #endif
+#ifndef TSAMD_GAMMA_SB_READLANE  // (experiment switch: 0 = the gamma step re-reads exp(Elogbeta) of the last pass from LDS at every use, for every K)
+#define TSAMD_GAMMA_SB_READLANE 1
+#endif
 #ifndef TSAMD_REPL_READLANE  // (experiment switch: 0 = the per-wave form broadcasts exp(Elogbeta) through its LDS row, as in rounds 3-4)
 #define TSAMD_REPL_READLANE 1
 #endif
@@ -984,6 +987,9 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   // the previous call's last SNP: its gamma step may be pending (column bits, exp(Elogbeta) of its last
   // pass), and its final values serve a first SNP at the same location
   uint2 pcodes = svalid ? load_codes(sloc) : make_uint2(0u, 0u);
+  // (per-wave form: lane j < 2K of every wave also keeps the exp(Elogbeta) the last executed pass used in a register -- eb_ran --,
+  // from which the gamma step takes it with v_readlane)
+  const double sb_state = S->eb[(tid & 63u) < J ? (tid & 63u) : 0u];
   if (tid < J) {
     s_sb[tid] = S->eb[tid];
     s_plam[tid] = svalid ? p.lam[(size_t)sloc * J + tid] : 0.0;
@@ -1039,7 +1045,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   uint32_t nword[kColAhead ? kItems : 1];
   // (default form: lam_old / eb_used live in lanes < 2K of EVERY wave and are advanced by the wave's own epilogue: lambda
   // before the pending pass' epilogue, exp(Elogbeta) of the pass that runs; eb_ran = what the last executed pass used)
-  double eb_ran = 0.0;
+  double eb_ran = sb_state;
   // the value whose epilogue this thread runs (J: none).  Shared form: thread j, value j.  Lane form: wave cb, lane 2 j' -> value
   // 16 cb + j' (where the exchange's sweep of column block cb leaves its total).
   auto epi_slot = [&]() -> uint32_t {
@@ -1290,6 +1296,12 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
 #else
       constexpr bool kLeanStep = PARTIAL || KT > 8;
 #endif
+      constexpr bool kSbScalar = kRepl && BSC && TSAMD_GAMMA_SB_READLANE != 0;
+      double sbs[kSbScalar ? J : 1];
+      if constexpr (kSbScalar) {
+#pragma unroll
+        for (int j = 0; j < (int)J; ++j) sbs[j] = lane_f64(eb_ran, j);
+      }
       auto gamma_one = [&](double (&gx)[KT], double (&wx)[KT], uint32_t nib, uint32_t &cn) {
         const double mom = (double)(nib & 3u), dad = (double)((nib >> 2) & 3u);
         const bool ok = (nib & 15u) != 0u;  // (an observed genotype has y + (2 - y) = 2)
@@ -1297,10 +1309,15 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         uint32_t zo = 0u;  // (opaque zero: exp(Elogbeta) is re-read from LDS where it is used, not held in 4K registers)
         asm volatile("" : "+v"(zo));
         const double *sbv = s_sb + zo;
+        // (per-wave form, K <= 8: the pairs sit in scalar registers for the whole step -- sbs, below -- instead of being re-read
+        // from LDS per item: every item's first instructions waited for those reads)
+        auto sb = [&](int j) -> double {
+          if constexpr (kSbScalar) return sbs[j]; else return sbv[j];
+        };
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-          s0 = fma(wx[k], sbv[2 * k], s0);
-          s1 = fma(wx[k], sbv[2 * k + 1], s1);
+          s0 = fma(wx[k], sb(2 * k), s0);
+          s1 = fma(wx[k], sb(2 * k + 1), s1);
         }
         const double rho = ok ? fast_rsqrt(p.nodetau0 + (double)cn) : 0.0;
         if constexpr (kLeanStep) {
@@ -1310,12 +1327,12 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
           const double inv = fast_rcp(s0 * s1) * (rho * p.gamma_scale);
           const double c0 = (mom * s1) * inv, c1 = (dad * s0) * inv, keep = 1.0 - rho, ra = rho * p.alpha;
 #pragma unroll
-          for (int k = 0; k < KT; ++k) gx[k] = fma(wx[k], fma(c0, sbv[2 * k], c1 * sbv[2 * k + 1]), fma(keep, gx[k], ra));
+          for (int k = 0; k < KT; ++k) gx[k] = fma(wx[k], fma(c0, sb(2 * k), c1 * sb(2 * k + 1)), fma(keep, gx[k], ra));
         } else {  // (the literal form, seven instructions per population: the full-size K <= 8 instantiation spills with the other)
           const double c0 = mom * fast_rcp(s0), c1 = dad * fast_rcp(s1);
 #pragma unroll
           for (int k = 0; k < KT; ++k) {
-            const double e = c0 * (wx[k] * sbv[2 * k]) + c1 * (wx[k] * sbv[2 * k + 1]);
+            const double e = c0 * (wx[k] * sb(2 * k)) + c1 * (wx[k] * sb(2 * k + 1));
             gx[k] += rho * (p.alpha + p.gamma_scale * e - gx[k]);
           }
         }
