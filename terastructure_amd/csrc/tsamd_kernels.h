@@ -115,31 +115,6 @@ __device__ __forceinline__ void epilogue_values_reg(const DevParams &p, uint32_t
   eb_new = (z1 * fast_rcp(z2)) * exp_nonpos(a1 - a2);
   diff = fabs(nw - lam_old);
 }
-// The same epilogue on the lanes that hold an in-launch exchange's totals (res_sum, tsamd_resident_kernels.h): value
-// j = 16 cb + j' of a column block sits in lane 2 j', so a population's pair (k, 0), (k, 1) are lanes 4 k' and 4 k' + 2 and the
-// odd lanes are free.  Lane 4 k' + 1 (and 4 k' + 3, identically) evaluates the split exp(psi) of the PAIR SUM while its even
-// neighbours evaluate their own value's: one exp_digamma_split on the critical path of a pass instead of two, and no trip
-// through LDS between the exchange and the epilogue.  Called by all 64 lanes; results are meaningful in even lanes whose
-// value exists.  Same operations on the same values as epilogue_values_reg -- the same bits: the pair sum is nw_a + nw_b in
-// either order (fma(1, b, a) in the odd lanes), an even lane's own value is nw + 0 * (its finite partner).
-template <int CTRL>
-__device__ __forceinline__ double dpp_quad(double v) {
-  const unsigned long long u = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
-  return __longlong_as_double(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
-}
-__device__ __forceinline__ void epilogue_values_lane(const DevParams &p, uint32_t lane, double lt, double eb_used, double lam_old,
-                                                     double &nw, double &eb_new, double &diff) {
-  nw = fma(lt, eb_used, ((lane >> 1) & 1u) ? p.eta1 : p.eta0);
-  const double left = dpp_quad<0xA0 /* quad_perm [0,0,2,2] */>(nw), other = dpp_quad<0x0A /* quad_perm [2,2,0,0] */>(nw);
-  const double x = fma((double)(lane & 1u), other, left);  // even lanes: their own lambda; odd lanes: the pair sum
-  double z, a;
-  exp_digamma_split(x, z, a);
-  const double z2 = partner<1>(z), a2 = partner<1>(a);     // (even lanes: the pair sum's split, from the odd neighbour)
-  eb_new = (z * fast_rcp(z2)) * exp_nonpos(a - a2);
-  diff = fabs(nw - lam_old);
-}
 __device__ __forceinline__ void epilogue_values_at(const DevParams &p, uint32_t j, double lt, double eb_used, double lam_old,
                                                    double *s_lam, double *s_eb, double *s_diff) {
   double nw, eb_new, diff;

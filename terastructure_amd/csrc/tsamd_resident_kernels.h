@@ -23,14 +23,6 @@ namespace tsamd {
 #ifndef TSAMD_NOCOL_K
 #define TSAMD_NOCOL_K 0
 #endif
-// The K x 2 epilogue on the lanes that hold the exchange's totals (round 5; 1 = where the shared form runs, 2 = also where the
-// per-wave form runs).  Measured and NOT the default: what it saves -- a workgroup barrier, an LDS round trip, one of the two
-// exp(psi) evaluations -- comes back as time inside the exchange; N = 1M, K = 8: 73.2-73.3 us per update against 72.5-73.0 for
-// the shared form; N = 125K, K = 20: 60.1-60.8 against 59.9-60.7; per-wave form at N = 100K, K = 8: 40.0 against 41.5
-// (profiles/r05_experiments.md).
-#ifndef TSAMD_LANE_EPILOGUE
-#define TSAMD_LANE_EPILOGUE 0
-#endif
 #ifndef TSAMD_GAMMA_SB_READLANE  // (experiment switch: 0 = the gamma step re-reads exp(Elogbeta) of the last pass from LDS at every use, for every K)
 #define TSAMD_GAMMA_SB_READLANE 1
 #endif
@@ -258,47 +250,26 @@ __device__ __forceinline__ void res_post(unsigned long long *dst, uint32_t tag, 
 struct NoOverlap {
   __device__ __forceinline__ void operator()() const {}
 };
-// What happens to a total once a wave has it: `sink(region, cb, nvalid, lane, s)` is called by ALL lanes of the wave that
-// swept column block cb of `region`; lane 2 j' (j' < nvalid / 2) holds the total of value 16 cb + j' in s.  The default
-// stores the totals into s_tot for whoever reads them after the exchange's closing barrier; ts_schedule runs the K x 2
-// epilogue right there, on the lanes that hold the totals (LaneEpilogue below).
-struct StoreTotals {
-  double *s_tot;
-  uint32_t J;
-  __device__ __forceinline__ void operator()(uint32_t region, uint32_t cb, uint32_t nvalid, uint32_t lane, double s) const {
-    if (lane < nvalid && !(lane & 1u)) s_tot[region * J + 16u * cb + (lane >> 1)] = s;
-  }
-};
-template <int KT, int WR, int ONE = kResOneLevelGrid, class LAY = ResLay<KT>, class OV = NoOverlap, class SINK = StoreTotals>
+template <int KT, int WR, int ONE = kResOneLevelGrid, class LAY = ResLay<KT>, class OV = NoOverlap>
 __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, uint32_t tag, uint32_t width, double mine, uint32_t g, uint32_t m,
                                              uint32_t grid, double *s_tot /* [2][2K] */, int *s_alive /* [4], all 1 */, uint32_t tid,
-                                             unsigned long long code, unsigned long long ticks, OV overlap = OV(),
-                                             SINK sink = SINK{nullptr, 0u}) {
+                                             unsigned long long code, unsigned long long ticks, OV overlap = OV()) {
   using L = LAY;
   constexpr uint32_t J = 2 * KT, RB = (uint32_t)res_blocks(KT), GR = L::GR;
   constexpr int kPerWave = (2 * (int)RB + 3) / 4;  // column blocks a wave sweeps at most
   constexpr bool kWideRow = J > 64u;  // a row wider than a wave (ts_holblock): ONE region, thread tid brings value tid
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   const uint32_t nblk = width * RB;
-  if constexpr (std::is_same<SINK, StoreTotals>::value) sink = StoreTotals{s_tot, J};
+  // a wave that has swept column block cb of `region` holds the total of value 16 cb + j' in lane 2 j' (j' < nvalid / 2)
+  auto sink = [&](uint32_t region, uint32_t cb, uint32_t nvalid, uint32_t ln, double sv) {
+    if (ln < nvalid && !(ln & 1u)) s_tot[region * J + 16u * cb + (ln >> 1)] = sv;
+  };
   if constexpr (WR == 0) {
     if (grid == 1u) {  // ONE workgroup (the smallest cohorts): its row is the total, nothing goes through memory
       const uint32_t region = kWideRow ? 0u : tid >> 6, j = kWideRow ? tid : tid & 63u;
       if (region < width && j < J) s_tot[region * J + j] = mine;
       overlap();
       __syncthreads();
-      if constexpr (!std::is_same<SINK, StoreTotals>::value && !kWideRow) {
-        // (a sink that works on the totals where a sweep leaves them: hand them over in that layout)
-#pragma unroll
-        for (int u = 0; u < kPerWave; ++u) {
-          const uint32_t q = wave + 4u * (uint32_t)u;
-          if (q < nblk) {
-            const uint32_t rg = q / RB, cb = q % RB, nvalid = min(32u, 2u * J - 32u * cb);
-            sink(rg, cb, nvalid, lane, s_tot[rg * J + min(16u * cb + ((lane & 31u) >> 1), J - 1u)]);
-          }
-        }
-        __syncthreads();
-      }
       return true;
     }
   }
@@ -846,20 +817,12 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   // arrays, a barrier.
 #if defined(TSAMD_SHARED_EPILOGUE)  // (experiments)
   constexpr bool kRepl = false;
-#elif defined(TSAMD_REPL_ALL)
-  constexpr bool kRepl = KT <= 8;
 #else
   // (K > 8: measured neutral to 1.5 % slower -- wider rows, more lanes in the epilogue.  Round 5: with exp(Elogbeta) taken from the
   // lanes' registers -- TSAMD_REPL_READLANE -- the per-wave form wins on the full-size instantiation as well: N = 1M, K = 8
   // 72.7-73.0 against 73.6-74.0 us per update; until then it ran only below full size)
-  constexpr bool kRepl = KT <= 8 && TSAMD_LANE_EPILOGUE < 2;
+  constexpr bool kRepl = KT <= 8;
 #endif
-  // kLane (round 5): the wave that sweeps a column block of the exchange runs the K x 2 epilogue of that block's values on the
-  // lanes that hold their totals (epilogue_values_lane: value j of block cb in lane 2 (j % 16) of wave cb) and only the
-  // results -- lambda, exp(Elogbeta), |dlambda| -- go through LDS: one workgroup barrier and one LDS round trip per pass
-  // fewer than the shared form, and one exp(psi) evaluation instead of two on the critical path.  The thread that runs value
-  // ej's epilogue keeps that value's lambda / exp(Elogbeta) of the pending pass (lam_old / eb_used) in its registers.
-  constexpr bool kLane = !kRepl && TSAMD_LANE_EPILOGUE >= 1;
   __shared__ __attribute__((aligned(16))) double s_ebw[kWaves][J];
   __shared__ double s_diffw[kWaves][J];
   __shared__ double s_red[kWaves * J];
@@ -1046,16 +1009,6 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   // (default form: lam_old / eb_used live in lanes < 2K of EVERY wave and are advanced by the wave's own epilogue: lambda
   // before the pending pass' epilogue, exp(Elogbeta) of the pass that runs; eb_ran = what the last executed pass used)
   double eb_ran = sb_state;
-  // the value whose epilogue this thread runs (J: none).  Shared form: thread j, value j.  Lane form: wave cb, lane 2 j' -> value
-  // 16 cb + j' (where the exchange's sweep of column block cb leaves its total).
-  auto epi_slot = [&]() -> uint32_t {
-    if constexpr (kLane) {
-      const uint32_t ln = tid & 63u, ej = 16u * (tid >> 6) + (ln >> 1);
-      return (ln & 1u) == 0u && ln < 32u && ej < J ? ej : J;
-    } else {
-      return tid < J ? tid : J;
-    }
-  };
   auto begin_pass = [&]() {
     fresh();
     iters += 1u;
@@ -1063,9 +1016,8 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     if constexpr (kRepl) {
       eb_ran = eb_used;  // (the epilogue advances eb_used; the next SNP's gamma step needs what the LAST pass used)
     } else {
-      const uint32_t ej = epi_slot();
-      lam_old = s_lam[ej < J ? ej : 0u];
-      eb_used = s_eb[ej < J ? ej : 0u];
+      lam_old = s_lam[tid < J ? tid : 0u];
+      eb_used = s_eb[tid < J ? tid : 0u];
     }
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
@@ -1135,7 +1087,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     }
     if (defer) {  // the SNP's last pass under the cap: its row and its epilogue's inputs wait for the next exchange
       if (tid < J) s_drow[tid] = mine;
-      if (const uint32_t ej = epi_slot(); ej < J) s_dlam[ej] = lam_old;
+      if (tid < J) s_dlam[tid] = lam_old;
       complete = true;
       return true;  // (the caller's end-of-SNP barrier orders these stores)
     }
@@ -1151,36 +1103,8 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
     }
     xcount += 1u;
     const uint32_t tag = xseq0 + xcount;
-    if constexpr (kLane) {
-      // the epilogue of a column block's values, run by the wave that swept it, on the lanes that hold the totals; region 1 =
-      // the deferred last pass of the previous SNP (workgroup 0 only: its inputs wait in s_sb / s_dlam)
-      auto sink = [&](uint32_t region, uint32_t cb, uint32_t nvalid, uint32_t ln, double sv) {
-        const uint32_t j = 16u * cb + ((ln & 31u) >> 1);
-        const bool has = ln < nvalid && !(ln & 1u);
-        double nw, ebn, df;
-        if (region == 0u) {
-          epilogue_values_lane(p, ln, sv, eb_used, lam_old, nw, ebn, df);
-          if (has) {
-            s_lam[j] = nw;
-            s_eb[j] = ebn;
-            s_diff[j] = df;
-          }
-        } else {
-          const uint32_t jj = has ? j : 0u;
-          epilogue_values_lane(p, ln, sv, s_sb[jj], s_dlam[jj], nw, ebn, df);
-          if (has) {
-            s_dolam[j] = nw;
-            s_doeb[j] = ebn;
-          }
-        }
-      };
-      if (!res_exchange<KT, WR, kResOneLevelGrid, ResLay<KT>, NoOverlap, decltype(sink)>(xb, p, tag, width, mine, g, m, gridDim.x, s_tot, s_alive, tid,
-                                                                                       fail_code(tag, false, par, serial), kResWaitTicks, NoOverlap(), sink))
-        return false;
-    } else {
-      if (!res_exchange<KT, WR>(xb, p, tag, width, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial), kResWaitTicks))
-        return false;
-    }
+    if (!res_exchange<KT, WR>(xb, p, tag, width, mine, g, m, gridDim.x, s_tot, s_alive, tid, fail_code(tag, false, par, serial), kResWaitTicks))
+      return false;
 #ifdef TSAMD_SCHED_TIME
     const unsigned long long te0 = wall_clock64();
     tk_xchg += te0 - tx0;
@@ -1210,12 +1134,10 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       }
       complete = epilogue_complete(p, iters, J, s_diffw[wave]);
     } else {
-    if constexpr (!kLane) {
-      if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);
-      if (deferred && blockIdx.x == 0 && tid >= 64u && tid < 64u + J)  // the previous SNP's final epilogue, beside the new pass' one
-        epilogue_values_at(p, tid - 64u, s_tot[J + tid - 64u], s_sb[tid - 64u], s_dlam[tid - 64u], s_dolam, s_doeb, s_ddiff);
-      __syncthreads();
-    }  // (lane form: the epilogues ran inside the exchange, ahead of its closing barrier)
+    if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);
+    if (deferred && blockIdx.x == 0 && tid >= 64u && tid < 64u + J)  // the previous SNP's final epilogue, beside the new pass' one
+      epilogue_values_at(p, tid - 64u, s_tot[J + tid - 64u], s_sb[tid - 64u], s_dlam[tid - 64u], s_dolam, s_doeb, s_ddiff);
+    __syncthreads();
     if (deferred) {
       if (blockIdx.x == 0) {  // publish the previous SNP (before this workgroup joins the next exchange)
         if (tid < J) {
@@ -1227,11 +1149,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       }
       deferred = false;
     }
-#ifdef TSAMD_SEQ_DECISION  // (experiment: the sequential sum for every K)
-    complete = epilogue_complete(p, iters, J, s_diff);
-#else
     if constexpr (KT > 8) complete = epilogue_complete_wave<J>(p, iters, s_diff, tid & 63u); else complete = epilogue_complete(p, iters, J, s_diff);
-#endif
     }
 #ifdef TSAMD_SCHED_TIME
     tk_epi += wall_clock64() - te0;
@@ -1449,11 +1367,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if constexpr (kLane) {
-      if (const uint32_t ej = epi_slot(); ej < J) s_sb[ej] = eb_used;
-    } else {
-      if (tid < J) s_sb[tid] = kRepl ? eb_ran : eb_used;
-    }
+    if (tid < J) s_sb[tid] = kRepl ? eb_ran : eb_used;
     if (tid < J) {
       s_plam[tid] = fin_lam;  // (deferred: not the final values, and never read -- the next SNP is elsewhere)
       s_peb[tid] = fin_eb;
