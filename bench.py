@@ -365,23 +365,27 @@ def schedule_roofline(prs, ran, nsteps, rec, stale, k, sc, geo, read_us):
     launch_s = prs["pass_ms"] / prs["pass_launches"] * 1e-3
     upd = nsteps / prs["pass_launches"]
     ppu = ran / nsteps                                   # passes per update
-    # (1) what binds it: fp64 vector arithmetic at one wave per SIMD.  Flops per update from the SQ counters of
-    # a profiled launch when a record for this (N, K) is committed (profiles/pass_kernel_pmc.json, built from
-    # rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64), else the hand count of the kernel's own
+    # (1) what binds it: fp64 vector arithmetic at one wave per SIMD.  Flops per update: the count of the kernel's own
     # formulation (FMA = 2): a sweep is 8K + 12 per individual (two K-term normalisers, ONE reciprocal of their
     # product with its third-order step, 2K accumulations per parent), the gamma step 89K + 25 (normalisers 4K,
     # update 7K -- 10K in the full-size K <= 8 instantiation, which keeps the literal form --, exp(psi) 78K).
     literal_step = k <= 8 and sc > 15 * 65536
     hand = ppu * sc * (8.0 * k + 12.0) + sc * ((92.0 if literal_step else 89.0) * k + 25.0)
-    flops = rec.get("fp64_flops_per_update")
-    if flops:
-        flops_src = ("SQ_INSTS_VALU_*_F64 counters of a profiled launch committed under profiles/ (constants of "
-                     "profiles/pass_kernel_pmc.json, guarded by a hash of the kernel sources -- not measured in this run): "
-                     + ", ".join(rec.get("flops_source_files", [])))
-    else:
-        flops = hand
-        flops_src = ("hand count of the kernel's formulation (" + (stale[0] or "no counter record for this N, K, GPU count in "
-                     "profiles/pass_kernel_pmc.json") + ")")
+    # `achieved` / `frac` use the ALGORITHMIC count (the formulation's flops, computed here from this run's pass counts).
+    # The counters of a profiled launch (when a record for this shape is committed) give what the kernel EXECUTED, reported
+    # beside it: wave instructions x 64 lanes, which also prices the K x 2 epilogues -- 2K active lanes of a wave, run by all
+    # four waves of all workgroups -- at full width (18 % above the algorithmic count at N = 1M, K = 8).
+    flops = hand
+    flops_src = ("algorithmic: the formulation's flops, FMA = 2 -- per update passes x N x (8K + 12) for the sweeps + N x (89K + 25) "
+                 "for the gamma step (92K in the full-size K <= 8 instantiation), from THIS run's pass count")
+    executed = rec.get("fp64_flops_per_update")
+    executed_src = None
+    if executed:
+        executed_src = ("SQ_INSTS_VALU_*_F64 counters of a profiled launch committed under profiles/ (constants of "
+                        "profiles/pass_kernel_pmc.json, guarded by a hash of the kernel sources -- not measured in this run): "
+                        + ", ".join(rec.get("flops_source_files", [])))
+    elif stale[0]:
+        executed_src = stale[0]
     tflops = flops * upd / launch_s / 1e12
     # (2) memory: what the kernel itself must move per update -- gamma and c_n, read and written, of the items
     # whose gamma is not kept in LDS, one 2-bit column -- and what the counters saw
@@ -401,7 +405,10 @@ def schedule_roofline(prs, ran, nsteps, rec, stale, k, sc, geo, read_us):
         "achieved": round(tflops, 2), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4),
         "traffic": None if traffic is None else traffic * upd,
-        "flops_per_update": flops, "flops_per_update_hand_count": hand, "flops_source": flops_src,
+        "flops_per_update": flops, "flops_source": flops_src,
+        "executed": {"flops_per_update": executed, "achieved": None if not executed else round(executed * upd / launch_s / 1e12, 2),
+                     "frac": None if not executed else round(executed * upd / launch_s / 1e12 / FP64_VALU_PEAK_TFLOPS, 4),
+                     "unit": "TFLOP/s", "source": executed_src},
         "measured_in_this_run": "avg_launch_us (HIP events on the engine's stream around every launch of the timed kernel)",
         "avg_launch_us": round(launch_s * 1e6, 1), "launches_timed": prs["pass_launches"], "updates_per_launch": upd,
         "per_update_us": round(launch_s * 1e6 / upd, 3), "passes_per_update": round(ppu, 3),
@@ -453,8 +460,7 @@ def schedule_roofline(prs, ran, nsteps, rec, stale, k, sc, geo, read_us):
                                             "(passes + 1) N / 4 (columns)"),
                  "streamed_individuals": int(streamed), "on_chip_individuals": int(on_chip)}
         if streamed > 0:   # memory binds: the streamed weights and the gamma step's streams
-            fp64 = {key: roofline[key] for key in ("achieved", "peak", "unit", "frac", "flops_per_update", "flops_per_update_hand_count",
-                                                   "flops_source")}
+            fp64 = {key: roofline[key] for key in ("achieved", "peak", "unit", "frac", "flops_per_update", "flops_source", "executed")}
             fp64["bound"] = "fp64_valu"
             roofline.update(hbm_h)
             roofline.update({

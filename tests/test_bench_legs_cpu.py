@@ -151,7 +151,7 @@ def test_one_failing_leg_costs_only_itself(tmp_path, fail_leg, fail_rank):
     if fail_leg != "roofline_timed_kernel":
         rf = m["roofline"]                                          # the timed kernel's roofline: from the timed mode alone
         assert rf is not None and rf["bound"] == "fp64_valu" and rf["avg_launch_us"] == 2000.0 and rf["launches_timed"] == 1
-        assert rf["updates_per_launch"] == 12 and rf["launch_per_snp"] is None and "hand count" in rf["flops_source"]
+        assert rf["updates_per_launch"] == 12 and rf["launch_per_snp"] is None and "algorithmic" in rf["flops_source"] and rf["executed"]["flops_per_update"] is None
         assert legs["roofline_timed_kernel"] == "ok"
     else:
         assert m["roofline"] is None and legs["roofline_timed_kernel"].startswith("failed")

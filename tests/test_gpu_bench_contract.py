@@ -36,7 +36,7 @@ def test_bench_json_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf and 0.0 < rf["frac"] < 1.0
     assert "N=30000 K=8" in d["metric"]                                       # names the workload that ran
     assert "ts_schedule" in rf["kernel"] and rf["updates_per_launch"] == 60 and rf["launches_timed"] == 1
-    assert rf["flops_per_update"] > 0 and rf["flops_source"]
+    assert rf["flops_per_update"] > 0 and "algorithmic" in rf["flops_source"] and "flops_per_update" in rf["executed"]
     hb = rf["hbm"]
     assert hb["bound"] == "hbm" and hb["peak"] == 8000.0 and hb["unit"] == "GB/s" and 0.0 < hb["moved_frac"] < 1.0
     # (K = 8: gamma and c_n of 9 of a thread's 16 individuals stay in LDS)
@@ -61,7 +61,7 @@ def test_bench_json_contract():
     assert set(om) == {"launch_per_snp", "launch_per_pass"} and all(o["ok"] and o["c_n_equal"] for o in om.values())
     assert pv["kernels_per_snp"] == 0 and om["launch_per_snp"]["kernels_per_snp"] == 2 and om["launch_per_pass"]["kernels_per_snp"] == 10
     assert sum(d["inner_passes_histogram"].values()) == 60
-    assert isinstance(rf["counter_records"], str) and rf["counter_records"]      # fresh, absent for this shape, or stale (then: hand count)
+    assert isinstance(rf["counter_records"], str) and rf["counter_records"]      # fresh, absent for this shape, or stale (then: no `executed` figures)
     vb = d["validation_block"]                                                # floor(0.005 L) = 5 locations x N / 100 held-out individuals
     assert vb["locations"] == 5 and vb["heldout_per_location"] == 300 and vb["kernel"].startswith("ts_holblock<8>: 16 locations")
     assert vb["seconds_per_report"] > 0 and vb["entry_by_entry_seconds_per_report"] > 0 and vb["evaluation_only_seconds"] >= 0

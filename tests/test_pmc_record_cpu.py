@@ -1,6 +1,6 @@
 """The committed counter records (profiles/pass_kernel_pmc.json) carry a hash of the device sources they were
 collected from; bench.py uses their traffic / flops / latency figures only while the tree's sources still hash to it
-(a kernel change without re-profiling must not silently skew roofline.frac: it falls back to the hand count and says so)."""
+(a kernel change without re-profiling must not silently skew roofline.frac: the counter-based figures are dropped and the line says so)."""
 import json
 import os
 import shutil
