@@ -5,7 +5,7 @@
 // locations are independent.  ts_holblock (tsamd_holblock_kernels.h) runs such a block BX locations at a time for shards whose
 // weights fit the register file.  A context that runs ts_hybrid -- N = 1M, K = 20 on one GPU: 160 MB of weights against a
 // 128 MB register file -- ran the block entry by entry until round 5: 191 us per location, ten sweeps each re-reading the
-// streamed half of the weights, ten exchanges.  This kernel batches it (123 us):
+// streamed half of the weights, ten exchanges.  This kernel batches it (118 us):
 //   * nothing is modified in validation mode and no gamma is needed, so the residency split is chosen for THIS kernel:
 //     hh_reg_items(K) items of a thread in registers, hh_lds_items(K) in LDS (what the 160 KB hold beside the batch's
 //     arrays), every further item streamed from memory (Infinity Cache) through two buffers, one item ahead;
@@ -27,9 +27,14 @@
 namespace tsamd {
 
 // locations per sweep: as many as the register file takes beside a useful number of register items
-// (three at K = 20 would cut the streamed bytes per location by a third, but three locations' accumulators do not fit beside two
-// stream buffers: 39-45 spilled registers, 177 against 123 us per location -- profiles/r05_experiments.md)
+// (three at K = 20 would cut the streamed bytes per location by a third, but the third location's accumulators live in AGPRs:
+// 600 instructions per item, 185 of them register moves -- 174 against 118 us per location, with or without register items,
+// profiles/r05_experiments.md)
+#ifdef TSAMD_HH_SUB  // (experiments)
+constexpr int hh_sub(int) { return TSAMD_HH_SUB; }
+#else
 constexpr int hh_sub(int k) { return k <= 4 ? 4 : k <= 20 ? 2 : 1; }
+#endif
 // exp(Elogbeta) of the sub-batch in vector registers for the sweep (else read as pairs from LDS at each use)
 constexpr bool hh_bs(int k) { return k <= 8; }
 // locations per exchange: a multiple of that, at most 16, rows of at most 256 values
@@ -46,7 +51,7 @@ constexpr int hh_batch(int k) {
 constexpr int hh_budget(int) { return TSAMD_HH_BUDGET; }
 #else
 constexpr int hh_budget(int k) {
-  return k <= 8 ? 190 : k <= 10 ? 140 : k <= 13 ? 150 : k <= 14 ? 160 : k <= 15 ? 175 : k <= 16 ? 190 : k <= 20 ? 165 : k <= 23 ? 140 : k <= 24 ? 165 : k <= 27 ? 130 : k <= 28 ? 165 : 100;
+  return k <= 8 ? 190 : k <= 10 ? 140 : k <= 13 ? 150 : k <= 14 ? 160 : k <= 15 ? 175 : k <= 16 ? 190 : k <= 20 ? 185 : k <= 23 ? 140 : k <= 24 ? 165 : k <= 27 ? 130 : k <= 28 ? 165 : 100;
 }
 #endif
 constexpr int hh_reg_items(int k) {
@@ -288,19 +293,22 @@ __global__ __launch_bounds__(256, 1) void ts_hybhol(Ctl *ctl_a, const double *w_
           consume(wcur, nib);
           __builtin_amdgcn_sched_barrier(0);
         }
-        // streamed items, in index order, through two buffers, one item ahead
+        // streamed items, in index order, through two buffers, one item ahead.  The requests are UNCONDITIONAL (past the end:
+        // the last item again, from the L2): behind a branch the compiler can only wait for ALL outstanding loads where the
+        // paths join (s_waitcnt vmcnt(0): the request just issued included), and every second item's load stopped overlapping
+        // the arithmetic (round 5: 1.5 -> 1.2 us per streamed item)
 #pragma unroll 1
         for (uint32_t s = 0; s < scnt_wg; s += 2u) {
           fresh();
           uint32_t nib[BA];
-          if (s + 1u < scnt_wg) load_streamed(s + 1u, sbuf, wordb);
+          load_streamed(s + 1u, sbuf, wordb);
           __builtin_amdgcn_sched_barrier(0);
           streamed_codes(s, worda, nib);
           consume(sa, nib);
           __builtin_amdgcn_sched_barrier(0);
           if (s + 1u >= scnt_wg) break;
           fresh();
-          if (s + 2u < scnt_wg) load_streamed(s + 2u, sa, worda);
+          load_streamed(s + 2u, sa, worda);
           __builtin_amdgcn_sched_barrier(0);
           streamed_codes(s + 1u, wordb, nib);
           consume(sbuf, nib);

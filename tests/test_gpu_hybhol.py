@@ -27,7 +27,7 @@ def hh_split(k):
     hh_reg_items / hh_lds_items in csrc/tsamd_hybhol_kernels.h"""
     ba = 4 if k <= 4 else 2 if k <= 20 else 1
     bx = max(1, min(128 // (k * ba), 16 // ba)) * ba
-    budget = (190 if k <= 8 else 140 if k <= 10 else 150 if k <= 13 else 160 if k <= 14 else 175 if k <= 15 else 190 if k <= 16 else 165 if k <= 20
+    budget = (190 if k <= 8 else 140 if k <= 10 else 150 if k <= 13 else 160 if k <= 14 else 175 if k <= 15 else 190 if k <= 16 else 185 if k <= 20
               else 140 if k <= 23 else 165 if k <= 24 else 130 if k <= 27 else 165 if k <= 28 else 100)
     fixed = ba * 2 * k + (ba * 2 * k if k <= 8 else 0) + 2 * k
     reg = max(0, min(16, (budget - fixed) // k))
