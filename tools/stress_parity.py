@@ -1,4 +1,4 @@
-"""Randomised parity stress (tests/stress_cases.py; a fixed-seed 12-case slice of it runs in the suite,
+"""Randomised parity stress (tests/stress_cases.py; a fixed-seed 8-case slice of it runs in the suite,
 tests/test_gpu_geometry.py::test_random_geometries_slice).  python tools/stress_parity.py [cases] [seed]"""
 import os, sys
 import numpy as np
