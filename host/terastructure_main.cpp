@@ -29,12 +29,17 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <sstream>
 #include <string>
 #include <vector>
 
+#include "fast_format.h"
+#include "model_writer.h"
 #include "tsamd.h"
 
 namespace {
@@ -129,8 +134,15 @@ struct Options {
   bool ingest_only = false;     // extension: read the genotypes into HBM, write param.txt, stop (ingest measurement)
 };
 
+struct Timing {
+  double ingest = 0, validation_sample = 0, init_gamma = 0, training = 0, report = 0, save_blocking = 0, save_writer = 0, save_wait = 0;
+  uint32_t reports = 0, saves = 0;
+};
+
 struct Run {
   Options o;
+  Timing tm;
+  ModelWriter writer;
   std::string prefix;  // run directory
   FILE *plog = nullptr, *logf = nullptr, *vf = nullptr;
   tsamd_ctx *ctx = nullptr;            // shard 0 (the only one on a single GPU)
@@ -170,6 +182,7 @@ struct Run {
 [[noreturn]] void die(Run &r, const char *what) {
   fprintf(stderr, "error: %s: %s\n", what, tsamd_last_error(r.ctx));
   r.lerr("error: %s: %s", what, tsamd_last_error(r.ctx));
+  r.writer.stop();  // (a snapshot already handed over is written out completely: no half-written gamma.txt)
   exit(-1);
 }
 #define TS(r, call)               \
@@ -626,31 +639,60 @@ std::string add_iter_suffix(const Run &r, const char *c) {
 }
 
 // save_gamma (src/snpsamplinge.cc:546-576)
+// The main thread snapshots gamma / theta; the writer thread formats and writes them (ModelWriter above) while the next
+// schedules run.  The file names are fixed here (-file-suffix: the iteration of THIS save).
 void save_model(Run &r) {
+  Stopwatch sw;
   const size_t n = r.o.n, k = r.o.k;
-  std::vector<double> g(n * k), t(n * k);
+  std::unique_ptr<SaveJob> job(new SaveJob);
+  job->n = n;
+  job->k = k;
+  job->g.resize(n * k);
+  job->t.resize(n * k);
+  job->gamma_path = add_iter_suffix(r, "/gamma");
+  job->theta_path = add_iter_suffix(r, "/theta");
   for (size_t i = 0; i < r.ctxs.size(); ++i) {
     uint32_t b, c;
     shard_span(r, i, b, c);
-    TS(r, tsamd_get_gamma(r.ctxs[i], g.data() + (size_t)b * k));
-    TS(r, tsamd_get_theta(r.ctxs[i], t.data() + (size_t)b * k));
+    TS(r, tsamd_get_gamma(r.ctxs[i], job->g.data() + (size_t)b * k));
+    TS(r, tsamd_get_theta(r.ctxs[i], job->t.data() + (size_t)b * k));
   }
-  FILE *f = fopen(add_iter_suffix(r, "/gamma").c_str(), "w");
-  FILE *h = fopen(add_iter_suffix(r, "/theta").c_str(), "w");
-  if (!f || !h) {
-    r.lerr("cannot open gamma/theta file:%s\n", strerror(errno));
+  double waited = 0;
+  if (!r.writer.submit(std::move(job), &waited)) {
+    r.lerr("%s\n", r.writer.error().c_str());
     exit(-1);
   }
-  for (size_t i = 0; i < n; ++i) {
-    for (size_t j = 0; j < k; ++j) {
-      fprintf(f, "%.8f\t", g[i * k + j]);
-      fprintf(h, "%.8f\t", t[i * k + j]);
-    }
-    fprintf(f, "\n");
-    fprintf(h, "\n");
+  r.tm.save_wait += waited;
+  r.tm.save_blocking += sw.lap();
+  r.tm.saves++;
+}
+
+// every gamma.txt / theta.txt handed to the writer is complete and closed (before the process ends, on every path)
+void finish_saves(Run &r) {
+  double waited = 0;
+  const bool ok = r.writer.drain(&waited);
+  r.tm.save_wait += waited;
+  r.tm.save_blocking += waited;
+  r.tm.save_writer = r.writer.busy_seconds();
+  if (!ok) {
+    r.lerr("%s\n", r.writer.error().c_str());
+    fprintf(stderr, "%s\n", r.writer.error().c_str());
+    r.writer.stop();
+    exit(-1);
   }
+}
+
+void write_timing(Run &r) {
+  FILE *f = fopen(r.file_str("/timing.txt").c_str(), "w");
+  if (!f) return;
+  const Timing &t = r.tm;
+  fprintf(f, "# wall-clock seconds of this run (host/terastructure_main.cpp; not a reference file)\n");
+  fprintf(f, "ingest: %.3f\nvalidation sample: %.3f\ninit gamma: %.3f\ntraining: %.3f\nvalidation reports: %.3f (%u)\n", t.ingest, t.validation_sample,
+          t.init_gamma, t.training, t.report, t.reports);
+  fprintf(f, "save_model, main thread blocked: %.3f (%u saves; of which waiting for the writer: %.3f)\n", t.save_blocking, t.saves, t.save_wait);
+  fprintf(f, "save_model, writer thread busy (overlapped with training): %.3f\n", t.save_writer);
+  fprintf(f, "total: %u\n", r.duration());
   fclose(f);
-  fclose(h);
 }
 
 // compute_likelihood(first, validation = true) (src/snpsamplinge.cc:461-544);
@@ -708,24 +750,37 @@ void save_beta(Run &r, const std::vector<uint32_t> *locs) {
     r.lerr("cannot open beta or lambda file:%s\n", strerror(errno));
     exit(-1);
   }
+  // "%d\t" loc, K x "%.8f\t", "\n" (src/snpsamplinge.cc:761-798) -- through fmt_fixed8, a block of rows per fwrite
   const uint32_t chunk = 1u << 16;
   std::vector<double> eb((size_t)chunk * k);
+  std::vector<char> buf;
+  auto put_rows = [&](const uint32_t *ids, uint32_t first, uint32_t nl) {
+    buf.resize((size_t)nl * (k * (tsfmt::kMaxLen + 1) + 16));
+    char *p = buf.data();
+    for (uint32_t j = 0; j < nl; ++j) {
+      p = tsfmt::fmt_uint(p, ids ? ids[j] : first + j);
+      *p++ = '\t';
+      for (size_t q = 0; q < k; ++q) {
+        p = tsfmt::fmt_fixed8(p, eb[(size_t)j * k + q]);
+        *p++ = '\t';
+      }
+      *p++ = '\n';
+    }
+    if (fwrite(buf.data(), 1, (size_t)(p - buf.data()), f) != (size_t)(p - buf.data())) {
+      r.lerr("error writing beta file:%s\n", strerror(errno));
+      exit(-1);
+    }
+  };
   if (!locs) {
     for (uint32_t l0 = 0; l0 < r.o.l; l0 += chunk) {
       const uint32_t nl = std::min(chunk, r.o.l - l0);
       TS(r, tsamd_get_ebeta(r.ctx, l0, nl, eb.data()));
-      for (uint32_t j = 0; j < nl; ++j) {
-        fprintf(f, "%d\t", l0 + j);
-        for (size_t q = 0; q < k; ++q) fprintf(f, "%.8f\t", eb[(size_t)j * k + q]);
-        fprintf(f, "\n");
-      }
+      put_rows(nullptr, l0, nl);
     }
   } else {
     for (uint32_t loc : *locs) {
       TS(r, tsamd_get_ebeta(r.ctx, loc, 1, eb.data()));
-      fprintf(f, "%d\t", loc);
-      for (size_t q = 0; q < k; ++q) fprintf(f, "%.8f\t", eb[q]);
-      fprintf(f, "\n");
+      put_rows(&loc, 0, 1);
     }
   }
   fclose(f);
@@ -933,6 +988,7 @@ int main(int argc, char **argv) {
   }
 
   setup_run_dir(r);
+  Stopwatch phase;
   {  // SNP::read (src/snp.cc:9-21): the extension decides
     const std::string ext = o.datfname.size() >= 4 ? o.datfname.substr(o.datfname.size() - 4) : "";
     if (ext == ".bed") {
@@ -946,7 +1002,9 @@ int main(int argc, char **argv) {
       exit(-1);
     }
   }
+  r.tm.ingest = phase.lap();
   if (o.ingest_only) {
+    write_timing(r);
     destroy_all(r);
     return 0;
   }
@@ -1002,7 +1060,9 @@ int main(int argc, char **argv) {
     return 0;
   }
 
+  phase.lap();
   set_validation_sample(r, rng);
+  r.tm.validation_sample = phase.lap();
   {  // init_gamma (:226-237): n-major, k inner, Gamma(100 v, 0.01)
     std::vector<double> g((size_t)o.n * o.k);
     for (size_t i = 0; i < g.size(); ++i) {
@@ -1011,8 +1071,11 @@ int main(int argc, char **argv) {
     }
     set_gamma_all(r, g);
   }
+  r.tm.init_gamma = phase.lap();
   printf("+ computing initial heldout likelihood\n");
   compute_likelihood(r, true);
+  r.tm.report += phase.lap();
+  r.tm.reports++;
   save_model(r);
   printf("\n+ computing initial training likelihood\n+ done..\n+ initialization end\n");
   fflush(stdout);
@@ -1025,7 +1088,9 @@ int main(int argc, char **argv) {
     if (o.max_iter && r.iter + c > o.max_iter) c = o.max_iter > r.iter ? o.max_iter - r.iter : 0;
     std::vector<uint32_t> locs(c);
     for (uint32_t i = 0; i < c; ++i) locs[i] = rng.uniform_int(o.l);
+    phase.lap();
     if (c) run_batch(r, locs);
+    r.tm.training += phase.lap();
     r.iter += c;
     printf("\riteration = %d took %d secs", r.iter, r.duration());
     fflush(stdout);
@@ -1033,7 +1098,11 @@ int main(int argc, char **argv) {
       printf("iteration = %d took %d secs\n", r.iter, r.duration());
       r.lerr("iteration = %d took %d secs\n", r.iter, r.duration());
       r.lerr("computing heldout likelihood @ %d secs", r.duration());
-      if (compute_likelihood(r, false)) {
+      phase.lap();
+      const bool stop = compute_likelihood(r, false);
+      r.tm.report += phase.lap();
+      r.tm.reports++;
+      if (stop) {
         save_model(r);
         break;
       }
@@ -1047,6 +1116,8 @@ int main(int argc, char **argv) {
     }
   }
   printf("\n");
+  finish_saves(r);  // gamma.txt / theta.txt complete and closed before the process ends
+  write_timing(r);
   destroy_all(r);
   return 0;
 }

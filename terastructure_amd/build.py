@@ -5,6 +5,7 @@ The K-specialised kernels are compiled as one translation unit per K
 terastructure_amd/lib/obj and rebuilt when a source they include changes.
 """
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -32,10 +33,12 @@ def kernel_sources_sha():
     import hashlib
 
     h = hashlib.sha256()
-    # (the device headers AND the units that pick kernels and launch geometries: csrc/tsamd.hip and the per-K instantiation files)
-    for name in ("tsamd_device.h", "tsamd_kernels.h", "tsamd_resident_kernels.h", "tsamd_holblock_kernels.h", "tsamd_hybrid_kernels.h",
-                 "tsamd_hybhol_kernels.h", "tsamd.hip", "tsamd_inst.hip", "tsamd_sched.hip", "tsamd_hol.hip", "tsamd_hyb.hip", "tsamd_hhol.hip"):
-        h.update(open(os.path.join(CSRC, name), "rb").read())
+    # every device header, the units that pick kernels and launch geometries (csrc/*.hip) and the ABI header -- the advisor's
+    # round-5 finding: tsamd_generic_kernels.h / tsamd_wide_kernels.h were not covered
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
+    for path in [os.path.join(CSRC, f) for f in names] + [os.path.join(ROOT, "include", "tsamd.h")]:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -85,16 +88,25 @@ def _deps(src):
         try:
             text = open(f).read()
         except OSError:
+            # a dependency that cannot be read: depend on every header rather than on none
+            seen.update(HEADERS)
             continue
         for line in text.splitlines():
-            line = line.strip()
-            if line.startswith('#include "'):
-                name = line.split('"')[1]
-                for d in (CSRC, os.path.join(ROOT, "include")):
-                    cand = os.path.join(d, name)
-                    if os.path.exists(cand) and cand not in seen:
+            m = re.match(r'\s*#\s*include\s*"([^"]+)"', line)
+            if m is None:
+                if re.match(r"\s*#\s*include\s+[A-Za-z_]", line):  # an include through a macro: cannot be resolved here
+                    seen.update(HEADERS)
+                continue
+            name = m.group(1)
+            for d in (CSRC, os.path.join(ROOT, "include")):
+                cand = os.path.join(d, name)
+                if os.path.exists(cand):
+                    if cand not in seen:
                         seen.add(cand)
                         todo.append(cand)
+                    break
+            else:  # a project-style include that resolves to no file (generated header?): be conservative
+                seen.update(HEADERS)
     _DEPS[src] = sorted(seen)
     return _DEPS[src]
 

@@ -485,7 +485,8 @@ bool resident_geometry(uint32_t k, uint32_t npad, uint32_t cap, uint32_t *grid, 
     return (ch + (uint32_t)kResidentBlock - 1u) / (uint32_t)kResidentBlock;
   };
   uint32_t r = rounds(cap);
-  if (r > (uint32_t)resident_items((int)k)) return false;
+  // (a sharded launch -- one_gpu false -- holds sharded_items(K) items per thread: one fewer than resident_items(K) at K = 14 and 16)
+  if (r > (uint32_t)(one_gpu ? resident_items((int)k) : sharded_items((int)k))) return false;
   // Small shards on one GPU: up to kResOneLevelGrid workgroups exchange in ONE level (1.9 us against 3.0 per pass), which is
   // worth a few more individuals per thread -- each costs about 0.33 K us per update (gamma step + ten sweeps), the nine
   // shorter exchanges save about 10 (profiles/r03_experiments.md)

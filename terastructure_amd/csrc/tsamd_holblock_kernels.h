@@ -41,7 +41,7 @@ constexpr uint32_t kHolChunk = 1u << 14;
 template <int KT, int WR>
 __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
                                                       const uint32_t *sched, uint32_t n_sched, ResXchg *xb, uint32_t serial, const DevParams p) {
-  constexpr int BLOCK = 256, kWaves = BLOCK / 64, kItems = resident_items(KT);
+  constexpr int BLOCK = 256, kWaves = BLOCK / 64, kItems = sched_items(KT, WR);
   constexpr int BA = hol_sub(KT), BX = hol_batch(KT), NSUB = BX / BA, KX = BX * KT;
   constexpr uint32_t J = 2 * KT, JX = 2 * KX;
   constexpr bool BS = KT <= 24;  // exp(Elogbeta) of the sub-batch's locations in vector registers for the sweep

@@ -4,7 +4,7 @@
 // context drops to ten launches per update -- as soon as one individual more is asked for (K = 20: 327 680 per GPU).
 // The reference takes any -n / -k (src/main.cc:115-123).  This kernel keeps the same one-launch structure (gamma step,
 // passes, in-launch exchange, epilogue; same State in, same State out) and splits a thread's individuals three ways:
-//   * R = hy_reg_items(K) items in REGISTERS, as ts_schedule (one fewer above K = 20);
+//   * R = hy_reg_items(K) items in REGISTERS, as ts_schedule (one fewer above K = 20 and at K = 9);
 //   * Q = hy_lds_items(K) items whose weights live in LDS for the whole launch (the 160 KB that ts_schedule spends on
 //     half of gamma: a weight is read ten times per SNP, a gamma value once) -- K = 8: 9 items, K = 20: 3;
 //   * every further item STREAMED: its weights are re-read from memory (Infinity Cache) every pass through a
@@ -25,8 +25,11 @@ constexpr int hy_lds_items(int k) {
   const int n = (160 * 1024 - 1024 - 200 * k) / (k * 8 * 256);
   return n > 16 ? 16 : n;
 }
-// items in registers: ts_schedule's, one fewer above K = 20 (the streamed items' pipeline needs the registers)
-constexpr int hy_reg_items(int k) { return k <= 20 ? resident_items(k) : resident_items(k) - 1; }
+// items in registers: ts_schedule's, one fewer above K = 20 (the streamed items' pipeline needs the registers); round 6, from the
+// build's resource table (profiles/r06_kernel_resources.txt): K = 9 13 instead of 14 and K = 29 ... 32 one instead of two -- the
+// streamed instantiations of those K used 20 ... 236 bytes of scratch
+// (K = 22: floor(112 / 22) - 1 = 4, as before ts_schedule<22> went from 5 items to 4 in round 6)
+constexpr int hy_reg_items(int k) { return k == 9 ? 13 : k <= 20 ? resident_items(k) : k <= 24 ? 112 / k - 1 : k <= 28 ? 2 : 1; }
 // individuals a workgroup holds without streaming any weights
 constexpr int hybrid_resident_capacity(int k) { return (hy_reg_items(k) + hy_lds_items(k)) * kResidentBlock; }
 // streamed items per thread at most (a bound on the loop, not a register budget: 4M individuals per GPU at least)
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
   static_assert(resident_vec(KT) == 1 && R <= 16 && Q >= 1 && Q <= 16, "one individual per item; an item class's codes share one register");
   __shared__ __attribute__((aligned(16))) double s_eb[J];
   __shared__ __attribute__((aligned(16))) double s_sb[J];
-  __shared__ double s_lam[J], s_diff[J], s_tot[2 * J], s_plam[J], s_peb[J];
+  __shared__ double s_lam[J], s_diff[J], s_tot[res_tot_doubles<KT, WR>()], s_plam[J], s_peb[J];
   __shared__ double s_red[kWaves * J];
   __shared__ int s_alive[4];
   __shared__ double s_w[Q][KT][BLOCK];  // the weights of the LDS items
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybrid(Ctl *ctl_a, double *w_a, uin
                                                             kResWaitTicks, overlap))
       return false;
     TSAMD_HK(tk_xchg);
-    if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);
+    if (tid < J) epilogue_values(p, res_total<KT, WR>(s_tot, tid), eb_used, lam_old, s_lam, s_eb, s_diff);
     __syncthreads();
     complete = epilogue_complete(p, iters, J, s_diff);
     TSAMD_HK(tk_epi);

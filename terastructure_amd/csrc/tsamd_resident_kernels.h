@@ -38,9 +38,16 @@ constexpr int resident_vec(int k) { return k <= 8 ? TSAMD_RES_VEC : 1; }
 #else
 constexpr int resident_vec(int) { return 1; }
 #endif
-constexpr int resident_items(int k) { return k <= 8 ? 16 / resident_vec(k) : k <= 16 ? 128 / k : k <= 24 ? 112 / k : 3; }
+// (K = 22: 4, not floor(112 / 22) = 5 -- with 110 doubles of weights every ts_schedule<22> instantiation spilled 36 ... 76 bytes
+// to scratch: profiles/r06_kernel_resources.txt, round 6)
+constexpr int resident_items(int k) { return k <= 8 ? 16 / resident_vec(k) : k <= 16 ? 128 / k : k == 22 ? 4 : k <= 24 ? 112 / k : 3; }
 // individuals a workgroup can hold
 constexpr int resident_capacity(int k) { return resident_items(k) * resident_vec(k) * kResidentBlock; }
+// ... and what a thread of a SHARDED launch holds (ts_schedule<K, ., WR > 0>, ts_holblock<K, WR > 0>: the ranks' launches share one
+// geometry rule, resident_geometry in csrc/tsamd.hip): K = 16 one item less -- its 128 doubles of weights fill the AGPR half of the
+// register file, and the sharded exchange's few extra registers went to scratch (20 ... 52 bytes); K = 14 (9 x 14 = 126 doubles) likewise
+constexpr int sharded_items(int k) { return k == 16 ? 7 : k == 14 ? 8 : resident_items(k); }
+constexpr int sched_items(int k, int wr) { return wr > 0 ? sharded_items(k) : resident_items(k); }
 
 // ---- in-launch exchange -----------------------------------------------------------------------------------------
 // Per pass every workgroup contributes its partial row (2K doubles) and every workgroup gets the fixed-order total,
@@ -97,7 +104,34 @@ struct ResLay {
   static __device__ __forceinline__ unsigned long long *rank_sums(Xchg *x, uint32_t region, uint32_t slot, uint32_t row) {
     return x->res_sums + ((slot * 2u + region) * (uint32_t)(kMaxRanks * kResGroups) + row) * GR;
   }
+  // sharded, three levels, rows of at most two column blocks (res_split): the SECOND half's partial sum of a leader's level-2
+  // poll (the first goes to sums()), in the part of ResXchg::gran that rows of at most 64 granules leave unused
+  static __device__ __forceinline__ unsigned long long *sums_hi(ResXchg *xb, uint32_t region, uint32_t slot, uint32_t g) {
+    static_assert(GR > 64u || 2u * kRegion + 2u * 2u * (uint32_t)kResGroups * GR <= 2u * (uint32_t)kResRegionRows * (uint32_t)kResMaxGran,
+                  "the second halves' rows lie behind regions A and B");
+    return xb->gran + 2u * kRegion + ((region * 2u + slot) * (uint32_t)kResGroups + g) * GR;
+  }
 };
+// Sharded launches (WR > 0) whose rows have at most two column blocks (K <= 16) poll the world x 8 rows of level 2 in TWO
+// HALVES ON TWO WAVES side by side (round 6): a lane then holds WR / 2 row pairs in flight instead of WR (each an 8-byte
+// load, two registers) -- what the 8-rank instantiations of K <= 8 spilled to scratch for -- at the same single memory
+// round trip.  The halves' partial sums land in s_tot[i] and s_tot[4K + i]; res_total adds them (half 0 + half 1, the
+// same order on every rank).  Everything else: s_tot[i] is the total.
+template <int KT, int WR, class LAY = ResLay<KT>>
+constexpr bool res_split() {
+  return WR > 0 && res_blocks(KT) <= 2 && std::is_same<LAY, ResLay<KT>>::value;
+}
+template <int KT, int WR>
+__device__ __forceinline__ double res_total(const double *s_tot, uint32_t i) {
+  if constexpr (res_split<KT, WR>()) return s_tot[i] + s_tot[4u * (uint32_t)KT + i]; else return s_tot[i];
+}
+// rows of three or four column blocks (K >= 17) on 5 ... 8 ranks: every wave already polls a block of its own, 32 row pairs per
+// lane in one go -- except where that instantiation would spill to scratch (profiles/r06_kernel_resources.txt): two halves,
+// one after the other (one more memory round trip per exchange)
+constexpr bool res_seq_halves(int k) { return k == 18 || k == 16; }
+// doubles of s_tot a kernel with narrow rows of 2 KT values provides
+template <int KT, int WR>
+constexpr int res_tot_doubles() { return (res_split<KT, WR>() ? 8 : 4) * KT; }
 
 // the same row / sum / flat positions for rows of 2 KX values in ResXchg::wide (one region)
 template <int KX>
@@ -216,14 +250,18 @@ __device__ __forceinline__ bool res_sweep_blocks(const unsigned long long *base,
 // about as much as a hop of the exchange.  An even lane holds the low half and receives the high one; what the odd
 // lanes assemble from the same two words is not a number anybody reads.
 template <int N>
-__device__ __forceinline__ double res_sum(const unsigned (&v)[N], uint32_t lane) {
-  (void)lane;
-  double s = 0.0;
+__device__ __forceinline__ double res_rows_add(const unsigned (&v)[N], double s) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
     s += __longlong_as_double(((unsigned long long)other << 32) | v[i]);
   }
+  return s;
+}
+template <int N>
+__device__ __forceinline__ double res_sum(const unsigned (&v)[N], uint32_t lane) {
+  (void)lane;
+  const double s = res_rows_add<N>(v, 0.0);
   return pair_add<32>(s, s);  // own + lane ^ 32
 }
 
@@ -403,6 +441,59 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
         if (lane < nvalid && !(lane & 1u)) s_tot[16u * q + (lane >> 1)] = sv;
       }
     }
+  } else if constexpr (res_split<KT, WR, LAY>()) {
+    // sharded, rows of one or two column blocks: unit (block q, half h) = wave, wave + 4, ...; half h are rows
+    // [h WR, (h + 1) WR) of the world x 8 -- two waves poll a block side by side, WR / 2 row pairs per lane each
+    constexpr int H = WR / 2, kUnitsPerWave = (4 * (int)RB + 3) / 4;
+    const uint32_t rows_all = p.xchg_world * (uint32_t)kResGroups;
+#pragma unroll
+    for (int u = 0; u < kUnitsPerWave; ++u) {
+      const uint32_t unit = wave + 4u * (uint32_t)u, q = unit >> 1, h = unit & 1u;
+      if (q < nblk && (q < RB || blockIdx.x == 0)) {
+        const uint32_t region = q / RB, cb = q % RB, nvalid = min(32u, 2u * J - 32u * cb), row0 = h * (uint32_t)WR;
+        const uint32_t at = region * J + 16u * cb + (lane >> 1);
+        if (p.xchg_gather_leaders == 0u || m == 0u) {
+          double s;
+          if constexpr (WR == 32 && res_seq_halves(KT)) {  // (16 row pairs per lane are still too many for this instantiation: 8 + 8)
+            const uint32_t rows_h = rows_all > row0 ? rows_all - row0 : 0u;
+            unsigned va[H / 2];
+            alive = res_sweep<H / 2, __HIP_MEMORY_SCOPE_SYSTEM>(L::rank_sums(p.xchg, region, tag & 1u, row0), GR, 32u * cb, tag, nvalid, min(rows_h, (uint32_t)H), va,
+                                                                &xb->abort_word, p.host_error, code, ticks, lane) && alive;
+            double acc = res_rows_add<H / 2>(va, 0.0);
+            if (rows_h > (uint32_t)H) {  // (uniform)
+              unsigned vb[H / 2];
+              alive = res_sweep<H / 2, __HIP_MEMORY_SCOPE_SYSTEM>(L::rank_sums(p.xchg, region, tag & 1u, row0 + (uint32_t)H), GR, 32u * cb, tag, nvalid,
+                                                                  rows_h - (uint32_t)H, vb, &xb->abort_word, p.host_error, code, ticks, lane) && alive;
+              acc = res_rows_add<H / 2>(vb, acc);
+            }
+            s = pair_add<32>(acc, acc);
+          } else {
+          unsigned v2[H];
+          alive = res_sweep<H, __HIP_MEMORY_SCOPE_SYSTEM>(L::rank_sums(p.xchg, region, tag & 1u, row0), GR, 32u * cb, tag, nvalid,
+                                                          rows_all > row0 ? rows_all - row0 : 0u, v2, &xb->abort_word, p.host_error, code, ticks, lane) && alive;
+          s = res_sum<H>(v2, lane);
+          }
+          if (lane < nvalid && !(lane & 1u)) {
+            s_tot[h * 2u * J + at] = s;
+            // three levels (TSAMD_SCHEDULE_GATHER=leaders): the leader hands BOTH partial sums to the members of its group
+            if (p.xchg_gather_leaders != 0u)
+              res_post((h ? L::sums_hi(xb, region, tag & 1u, g) : L::sums(xb, region, tag & 1u, g)) + 32u * cb + lane, tag, s, 0);
+          }
+        } else if (h == 0u) {
+          // a member: its leader's two partial sums in one poll (lanes < 32 the first half's row, the others the second's);
+          // res_sum<1> adds them in the order res_total does
+          unsigned v1[1];
+          unsigned long long *lo = L::sums(xb, region, tag & 1u, g);
+          alive = res_sweep<1, __HIP_MEMORY_SCOPE_AGENT>(lo, (uint32_t)(L::sums_hi(xb, region, tag & 1u, g) - lo), 32u * cb, tag, nvalid, 2u, v1, &xb->abort_word,
+                                                         p.host_error, code, ticks, lane) && alive;
+          const double s = res_sum<1>(v1, lane);
+          if (lane < nvalid && !(lane & 1u)) {
+            s_tot[at] = s;
+            s_tot[2u * J + at] = 0.0;
+          }
+        }
+      }
+    }
   } else {
 #pragma unroll
   for (int u = 0; u < kPerWave; ++u) {
@@ -417,10 +508,27 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
         s = res_sum<kResGroups / 2>(v2, lane);
       } else if (p.xchg_gather_leaders == 0u || m == 0u) {
         // (every rank runs at least 8 workgroups -- the host checks -- so all world * 8 rows exist)
+        if constexpr (WR == 32 && (kWideRow || res_seq_halves(KT))) {
+          // up to 64 rows: polled in two halves one after the other -- 16 row pairs in flight per lane instead of 32, which
+          // these instantiations have no registers for (scratch otherwise) -- and added in the same order as in one go
+          const uint32_t rows_all = p.xchg_world * (uint32_t)kResGroups;
+          unsigned va[16];
+          alive = res_sweep<16, __HIP_MEMORY_SCOPE_SYSTEM>(L::rank_sums(p.xchg, region, tag & 1u, 0), GR, 32u * cb, tag, nvalid, min(rows_all, 32u), va,
+                                                           &xb->abort_word, p.host_error, code, ticks, lane) && alive;
+          double acc = res_rows_add<16>(va, 0.0);
+          if (rows_all > 32u) {  // (uniform: 5 ... 8 ranks)
+            unsigned vb[16];
+            alive = res_sweep<16, __HIP_MEMORY_SCOPE_SYSTEM>(L::rank_sums(p.xchg, region, tag & 1u, 32u), GR, 32u * cb, tag, nvalid, rows_all - 32u, vb,
+                                                             &xb->abort_word, p.host_error, code, ticks, lane) && alive;
+            acc = res_rows_add<16>(vb, acc);
+          }
+          s = pair_add<32>(acc, acc);
+        } else {
         unsigned v2[WR];
         alive = res_sweep<WR, __HIP_MEMORY_SCOPE_SYSTEM>(L::rank_sums(p.xchg, region, tag & 1u, 0), GR, 32u * cb, tag, nvalid,
                                                          p.xchg_world * (uint32_t)kResGroups, v2, &xb->abort_word, p.host_error, code, ticks, lane) && alive;
         s = res_sum<WR>(v2, lane);
+        }
         // three levels (TSAMD_SCHEDULE_GATHER=leaders): only the eight leaders of a rank poll the world x 8 rows; each hands
         // the total -- the same bits on every leader of every rank -- to the members of its group through its local row
         if (p.xchg_gather_leaders != 0u && lane < nvalid && !(lane & 1u)) res_post(L::sums(xb, region, tag & 1u, g) + 32u * cb + lane, tag, s, 0);
@@ -578,7 +686,9 @@ template <int KT>
 __global__ __launch_bounds__(256, 1) void ts_resident(Ctl *ctl_a, double *partials_a, double *w_a, uint32_t npad_a, uint32_t chunk_a,
                                                       uint32_t par_arg, uint32_t nrows_hint, ResXchg *xb, uint32_t serial, const DevParams p) {
   constexpr int BLOCK = 256, kWaves = BLOCK / 64, VEC = resident_vec(KT), kItems = resident_items(KT);
-  constexpr bool BS = KT <= 12, BSC = KT <= 8;  // (vector registers only up to K = 12 here: this kernel also holds the first sweep's loads in flight)
+  // (vector registers only up to K = 11 here -- this kernel also holds the first sweep's loads in flight -- and not at K = 9, whose
+  // 14 items leave no room for them either: 12 and 8 bytes of scratch at K = 9 and 12 until round 6)
+  constexpr bool BS = KT <= 8 || KT == 10 || KT == 11, BSC = KT <= 8;
   using LN = Lanes<VEC>;
   using WT = typename LN::T;
   using RC = ResCodes<VEC>;
@@ -796,7 +906,7 @@ constexpr int sched_next_streamed(int t, int lds, int items) {
 template <int KT, bool PARTIAL, int WR>
 __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, uint32_t npad_a, uint32_t chunk_a, uint32_t par_arg,
                                                       const uint32_t *sched, uint32_t n_sched, ResXchg *xb, uint32_t serial, const DevParams p) {
-  constexpr int BLOCK = 256, kWaves = BLOCK / 64, VEC = resident_vec(KT), kItems = resident_items(KT);
+  constexpr int BLOCK = 256, kWaves = BLOCK / 64, VEC = resident_vec(KT), kItems = sched_items(KT, WR);
   constexpr bool BS = KT <= 24, BSC = KT <= 8;  // exp(Elogbeta) of a pass in registers / in scalar registers
   using LN = Lanes<VEC>;
   using WT = typename LN::T;
@@ -806,7 +916,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   static_assert(VEC == 1 && kItems <= 16, "one individual per item; the items' genotype nibbles are packed into two registers");
   __shared__ __attribute__((aligned(16))) double s_eb[J];
   __shared__ __attribute__((aligned(16))) double s_sb[J];
-  __shared__ double s_lam[J], s_diff[J], s_tot[2 * J], s_plam[J], s_peb[J];
+  __shared__ double s_lam[J], s_diff[J], s_tot[res_tot_doubles<KT, WR>()], s_plam[J], s_peb[J];
   __shared__ double s_drow[J], s_dlam[J], s_dolam[J], s_doeb[J], s_ddiff[J];  // the deferred last pass of the previous SNP
   // kRepl: every WAVE runs the K x 2 epilogue of a pass for itself on lanes < 2K (same totals, same code, same bits) and
   // keeps lambda / exp(Elogbeta) of the pending pass in those lanes' registers: no workgroup barrier between the exchange
@@ -1001,9 +1111,10 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
   double lam_old = 0.0, eb_used = 0.0;
   double b0[BS ? KT : 1], b1[BS ? KT : 1], acc0[KT], acc1[KT];
   bool complete = false;
-  // every later SNP's column is requested while its predecessor runs -- except at K = 16, whose 128 resident doubles
-  // per thread leave no room for the words in flight (36 bytes of scratch otherwise): it loads them when the SNP starts
-  constexpr bool kColAhead = KT != 16 && KT != TSAMD_NOCOL_K;
+  // every later SNP's column is requested while its predecessor runs -- except where the instantiation has no room for the
+  // words in flight (K = 16 on one GPU: 128 resident doubles per thread, 36 bytes of scratch otherwise; K = 14: 126 doubles,
+  // 12 ... 44 bytes; K = 24 on two ranks: 12 bytes -- profiles/r06_kernel_resources.txt): those load them when the SNP starts
+  constexpr bool kColAhead = !(KT == 16 || KT == 14 || (KT == 24 && WR == 8)) && KT != TSAMD_NOCOL_K;
   uint2 codes = kColAhead ? load_codes(sched[0] & 0x7fffffffu) : make_uint2(0u, 0u);
   uint32_t nword[kColAhead ? kItems : 1];
   // (default form: lam_old / eb_used live in lanes < 2K of EVERY wave and are advanced by the wave's own epilogue: lambda
@@ -1113,7 +1224,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       const uint32_t lane = tid & 63u, wave = tid >> 6;
       if (lane < J) {
         double nw, ebn, df;
-        epilogue_values_reg(p, lane, s_tot[lane], eb_used, lam_old, nw, ebn, df);
+        epilogue_values_reg(p, lane, res_total<KT, WR>(s_tot, lane), eb_used, lam_old, nw, ebn, df);
         lam_old = nw;
         eb_used = ebn;
         if constexpr (!(BSC && TSAMD_REPL_READLANE)) s_ebw[wave][lane] = ebn;
@@ -1123,7 +1234,7 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
         if (blockIdx.x == 0) {  // the previous SNP's final epilogue and its publication: the second wave, from registers
           if (wave == 1u && lane < J) {
             double nw, ebn, df;
-            epilogue_values_reg(p, lane, s_tot[J + lane], s_sb[lane], s_dlam[lane], nw, ebn, df);
+            epilogue_values_reg(p, lane, res_total<KT, WR>(s_tot, J + lane), s_sb[lane], s_dlam[lane], nw, ebn, df);
             __hip_atomic_store(&p.lam[(size_t)dloc * J + lane], nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&p.eb[(size_t)dloc * J + lane], ebn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -1134,9 +1245,9 @@ __global__ __launch_bounds__(256, 1) void ts_schedule(Ctl *ctl_a, double *w_a, u
       }
       complete = epilogue_complete(p, iters, J, s_diffw[wave]);
     } else {
-    if (tid < J) epilogue_values(p, s_tot[tid], eb_used, lam_old, s_lam, s_eb, s_diff);
+    if (tid < J) epilogue_values(p, res_total<KT, WR>(s_tot, tid), eb_used, lam_old, s_lam, s_eb, s_diff);
     if (deferred && blockIdx.x == 0 && tid >= 64u && tid < 64u + J)  // the previous SNP's final epilogue, beside the new pass' one
-      epilogue_values_at(p, tid - 64u, s_tot[J + tid - 64u], s_sb[tid - 64u], s_dlam[tid - 64u], s_dolam, s_doeb, s_ddiff);
+      epilogue_values_at(p, tid - 64u, res_total<KT, WR>(s_tot, J + tid - 64u), s_sb[tid - 64u], s_dlam[tid - 64u], s_dolam, s_doeb, s_ddiff);
     __syncthreads();
     if (deferred) {
       if (blockIdx.x == 0) {  // publish the previous SNP (before this workgroup joins the next exchange)

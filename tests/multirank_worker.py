@@ -62,8 +62,11 @@ def main():
         assert kps == int(os.environ["TS_EXPECT_KPS"]), f"kernels per SNP: {kps}"
     if os.environ.get("TS_EXPECT_HYBRID"):    # the shard exceeds ts_schedule's register capacity: ts_hybrid (more individuals per thread than its register items)
         geo = eng.schedule_geometry()
-        reg_items = 16 if k <= 8 else 128 // k if k <= 16 else 112 // k if k <= 24 else 3
+        reg_items = 16 if k <= 8 else 128 // k if k <= 16 else 4 if k == 22 else 112 // k if k <= 24 else 3
         assert geo["indivs_per_thread"] > reg_items, geo
+    if os.environ.get("TS_EXPECT_PER_THREAD"):  # the instantiation a case means to run (16 at K <= 8: the one without the skip-unused-items branches)
+        geo = eng.schedule_geometry()
+        assert geo["indivs_per_thread"] == int(os.environ["TS_EXPECT_PER_THREAD"]), geo
     locs = np.random.default_rng(seed + 3).integers(0, l, size=nsnp).astype(np.uint32)
     switch = os.environ.get("TS_SWITCH_MODES") == "1"   # ts_schedule -> one launch per pass -> ts_schedule, mid-run
     eng.run_schedule(locs[:5])          # eager path
