@@ -149,6 +149,7 @@ struct Run {
   std::vector<tsamd_ctx *> ctxs;       // all shards, rank order
   time_t start_time = time(nullptr);
   uint32_t iter = 0;
+  uint32_t saved_iter = 0xffffffffu;  // iteration of the last save_model
   std::map<uint32_t, std::vector<uint32_t>> validation;  // loc -> ascending individuals
   // stop rule state (src/snpsamplinge.cc:26-31)
   double prev_h = -2147483647, max_h = -2147483647;
@@ -665,6 +666,7 @@ void save_model(Run &r) {
   r.tm.save_wait += waited;
   r.tm.save_blocking += sw.lap();
   r.tm.saves++;
+  r.saved_iter = r.iter;
 }
 
 // every gamma.txt / theta.txt handed to the writer is complete and closed (before the process ends, on every path)
@@ -1111,7 +1113,8 @@ int main(int argc, char **argv) {
       r.lerr("done @ %d secs", r.duration());
     }
     if (g_terminate || (o.max_iter && r.iter >= o.max_iter)) {
-      save_model(r);
+      // (a report that ended at this very iteration has just saved this state: the same bytes would be written again)
+      if (r.saved_iter != r.iter) save_model(r);
       break;
     }
   }

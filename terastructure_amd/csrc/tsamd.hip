@@ -456,7 +456,7 @@ void configure_launch(tsamd_ctx *c, uint32_t max_grid) {
   // device together -- a first pass that fills every compute unit (it is register-bound: one workgroup per unit from K = 12
   // on) would keep its peers' previous passes off the device until its bounded wait gives up (4 ranks x 250 000 individuals,
   // K = 20: "timed out waiting for a peer (epoch 2)").  Each rank gets its share of the workgroups.  One rank per device: 1.
-  const uint32_t share = std::max<uint32_t>(1u, std::max<uint32_t>(c->device_share, env_u32("TSAMD_DEVICE_SHARE", 1)));
+  const uint32_t share = std::max<uint32_t>(1u, c->device_share);
   geometry(p.npairs, block, env_u32("TSAMD_GRID", share > 1u ? std::max<uint32_t>(8u, 256u / share) : 256u), p.chunk, c->grid);
   // first pass: exactly as many workgroups as are resident at once (one round; the kernel is
   // register-bound, so that is 2 per compute unit at K = 8 and 1 from K = 12 on)
@@ -539,8 +539,8 @@ void choose_sharded_schedule(tsamd_ctx *c) {
     return;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, c->dev) != hipSuccess || prop.multiProcessorCount <= 0) return;
-  c->device_share = std::max<uint32_t>(c->device_share, env_u32("TSAMD_DEVICE_SHARE", 1));
-  const uint32_t cap = std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)prop.multiProcessorCount / c->device_share);
+  uint32_t cap = std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)prop.multiProcessorCount / c->device_share);
+  if (env_u32("TSAMD_SCHED_WORKGROUPS", 0) >= (uint32_t)kResGroups) cap = std::min<uint32_t>(cap, env_u32("TSAMD_SCHED_WORKGROUPS", 0));  // (tuning knob, see tsamd_create)
   if (cap < (uint32_t)kResGroups) return;
   uint32_t my_grid = 0, my_chunk = 0;
   bool hybrid = false;
@@ -771,6 +771,11 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
 
   tsamd_ctx *c = new tsamd_ctx();
   c->cfg = *cfg;
+  // Ranks that share one device (tests, rehearsals) say so with TSAMD_DEVICE_SHARE=<ranks>: read ONCE, here, for sharded contexts
+  // only -- every later decision (launch geometry, the sharded whole-schedule kernels, the geometry of a recovery) takes the share
+  // from the context, so the ranks of a run cannot drift apart through their environments after they were created (advisor, round 5).
+  // The ranks must be started with the same value; tsamd_p2p_connect_local sets it itself.
+  if (cfg->world > 1u) c->device_share = std::max<uint32_t>(1u, env_u32("TSAMD_DEVICE_SHARE", 1));
   c->dev = cfg->device;
   c->n_begin = b;
   c->n_local = cnt;
@@ -829,6 +834,9 @@ int tsamd_create(const tsamd_config *cfg, tsamd_ctx **out) {
     // (test hook: fewer workgroups than the device holds, so that small shards exercise the many-items-per-thread paths --
     // ts_hybrid's LDS and streamed items for every K -- at a size the oracle finishes in a moment)
     if ((cfg->flags & TSAMD_FLAG_TEST_HOOKS) && env_u32("TSAMD_TEST_MAX_WORKGROUPS", 0) > 0u) cus = std::min<int>(cus, (int)env_u32("TSAMD_TEST_MAX_WORKGROUPS", 0));
+    // (tuning knob, round 6's geometry sweep: at most this many workgroups for the resident kernels -- fewer members per exchange
+    // group against more individuals per thread; profiles/r06_experiments.md.  Every rank of a sharded run must see the same value)
+    if (env_u32("TSAMD_SCHED_WORKGROUPS", 0) >= (uint32_t)kResGroups) cus = std::min<int>(cus, (int)env_u32("TSAMD_SCHED_WORKGROUPS", 0));
     c->sched_grid = c->grid;
     c->sched_chunk = p.chunk;
     // (TSAMD_GRID / TSAMD_BLOCK shape the launch-per-pass kernels: a context they are set for runs those)
@@ -1376,6 +1384,7 @@ static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
   constexpr uint32_t kSerialMask = (1u << 30) - 1u;
   const uint32_t serial = (uint32_t)(code >> 34) & kSerialMask, par = (uint32_t)(code >> 33) & 1u;
   size_t at = c->journal.size();
+  bool shrunk = false;  // ranks sharing a device: the replay (and everything after it) runs on a reduced launch geometry
   uint32_t ahead = 0;  // launches of the failed schedule before the failed one
   for (size_t i = 0; i < c->journal.size(); ++i) {
     const tsamd_ctx::Journal &j = c->journal[i];
@@ -1412,10 +1421,17 @@ static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
     // compute units, one run in two).  The replay therefore runs on an eighth of each rank's share (every rank takes this
     // branch alike: the exchange's row layout stays consistent).  One rank per device: a pass kernel never waits for a
     // kernel that needs the same device, nothing to do.
-    const uint32_t share = std::max<uint32_t>(1u, std::max<uint32_t>(c->device_share, env_u32("TSAMD_DEVICE_SHARE", 1)));
-    hipDeviceProp_t prop;
-    if (share > 1u && hipGetDeviceProperties(&prop, c->dev) == hipSuccess && prop.multiProcessorCount > 0)
+    const uint32_t share = std::max<uint32_t>(1u, c->device_share);
+    if (share > 1u) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, c->dev) != hipSuccess || prop.multiProcessorCount <= 0) {
+        // (a rank that kept its grid while its peers shrank theirs would read mismatched rows: no silent skip)
+        c->recovering = false;
+        return fail(c, TSAMD_EHIP, "replay after a failed resident launch: cannot query device %d to size the replay's launches", c->dev);
+      }
       configure_launch(c, std::max<uint32_t>(4u, (uint32_t)prop.multiProcessorCount / (8u * share)));
+      shrunk = true;
+    }
   }
   c->q = par;  // the failed launch was to write the slot of this parity: the slot of the other one holds the state to go on from
   int rc = TSAMD_OK;
@@ -1463,7 +1479,8 @@ static int recover_from_failed_entry(tsamd_ctx *c, unsigned long long code) {
   c->recoveries++;
   fail(c, TSAMD_OK, "warning: %s could not get its %u workgroups resident at once (something else holds compute units of device %d); the "
        "schedule was replayed one launch per pass from the unchanged state and the context stays in that mode "
-       "(tsamd_set_launch_mode raises it again)", was_persistent ? (c->hybrid ? "ts_hybrid" : "ts_schedule") : "ts_resident", c->sched_grid, c->dev);
+       "(tsamd_set_launch_mode raises it again)%s", was_persistent ? (c->hybrid ? "ts_hybrid" : "ts_schedule") : "ts_resident", c->sched_grid, c->dev,
+       shrunk ? "; ranks sharing the device: the launch-per-pass kernels keep the reduced geometry of the replay (an eighth of each rank's share) from here on" : "");
   return TSAMD_OK;
 }
 

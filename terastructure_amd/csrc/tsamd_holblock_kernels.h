@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 1) void ts_holblock(Ctl *ctl_a, const double *
   constexpr bool BS = KT <= 24;  // exp(Elogbeta) of the sub-batch's locations in vector registers for the sweep
   static_assert(resident_vec(KT) == 1, "one individual per item");
   static_assert(JX <= (uint32_t)BLOCK && BX <= 16 && BX % BA == 0, "a batch's row is brought by one thread per value");
-  using Wide = WideLay<KX>;
+  using Wide = WideLay<KX, KT>;
   __shared__ __attribute__((aligned(16))) double s_eb[BX][J];  // exp(Elogbeta) the running pass uses, per location of the batch
   __shared__ double s_diff[BX][J];
   __shared__ double s_tot[JX > 4 * J ? JX : 4 * J];

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void ts_hybhol(Ctl *ctl_a, const double *w_
   constexpr bool BS = hh_bs(KT);
   static_assert(resident_vec(KT) == 1 && RQ <= 16 && RQ >= 1, "one individual per item; the on-chip items' codes share two registers");
   static_assert(JX <= (uint32_t)BLOCK && BX <= 16 && BX % BA == 0, "a batch's row is brought by one thread per value");
-  using Wide = WideLay<KX>;
+  using Wide = WideLay<KX, KT>;
   __shared__ __attribute__((aligned(16))) double s_eb[BX][J];  // exp(Elogbeta) the running pass uses, per location of the batch
   __shared__ double s_diff[BX][J];
   __shared__ double s_tot[JX > 4 * J ? JX : 4 * J];

@@ -88,6 +88,7 @@ struct ResXchg {
 };
 template <int KT>
 struct ResLay {
+  static constexpr int kSegK = KT;  // (see WideLay)
   static constexpr uint32_t GR = 32u * (uint32_t)res_blocks(KT);  // granules per row (row stride)
   static constexpr uint32_t kRegion = (uint32_t)kResRegionRows * GR;
   static __device__ __forceinline__ unsigned long long *rows(ResXchg *xb, uint32_t region, uint32_t g, uint32_t m) {
@@ -134,8 +135,11 @@ template <int KT, int WR>
 constexpr int res_tot_doubles() { return (res_split<KT, WR>() ? 8 : 4) * KT; }
 
 // the same row / sum / flat positions for rows of 2 KX values in ResXchg::wide (one region)
-template <int KX>
+// KS: the K of the context (rows of 2 KS values in its training kernels): a sharded exchange adds the ranks' rows in the order
+// those kernels do (res_segmented below), so that a batched validation block equals the entry-by-entry path bit for bit
+template <int KX, int KS = KX>
 struct WideLay {
+  static constexpr int kSegK = KS;
   static constexpr uint32_t GR = 32u * (uint32_t)res_blocks(KX);
   static_assert(GR <= (uint32_t)kResWideGran, "a wide row holds at most kResWideGran granules");
   static __device__ __forceinline__ unsigned long long *rows(ResXchg *xb, uint32_t, uint32_t g, uint32_t m) {
@@ -263,6 +267,24 @@ __device__ __forceinline__ double res_sum(const unsigned (&v)[N], uint32_t lane)
   (void)lane;
   const double s = res_rows_add<N>(v, 0.0);
   return pair_add<32>(s, s);  // own + lane ^ 32
+}
+
+// rows [A, B) of v added onto s in order
+template <int A, int B, int N>
+__device__ __forceinline__ double res_rows_add_range(const unsigned (&v)[N], double s) {
+  static_assert(A >= 0 && A <= B && B <= N, "range");
+#pragma unroll
+  for (int i = A; i < B; ++i) {
+    const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+    s += __longlong_as_double(((unsigned long long)other << 32) | v[i]);
+  }
+  return s;
+}
+// total of one SEGMENT of row pairs [A, B): (its even rows) + (its odd rows)
+template <int A, int B, int N>
+__device__ __forceinline__ double res_segment(const unsigned (&v)[N]) {
+  const double s = res_rows_add_range<A, B, N>(v, 0.0);
+  return pair_add<32>(s, s);
 }
 
 __device__ __forceinline__ void res_post(unsigned long long *dst, uint32_t tag, double v, int scope_system) {
@@ -508,26 +530,45 @@ __device__ __forceinline__ bool res_exchange(ResXchg *xb, const DevParams &p, ui
         s = res_sum<kResGroups / 2>(v2, lane);
       } else if (p.xchg_gather_leaders == 0u || m == 0u) {
         // (every rank runs at least 8 workgroups -- the host checks -- so all world * 8 rows exist)
-        if constexpr (WR == 32 && (kWideRow || res_seq_halves(KT))) {
+        // The ORDER of the sum is that of the context's training kernels (bit-for-bit equality of a batched validation block
+        // with the entry-by-entry path): where those split level 2 into two halves (res_split: K <= 16) the total is
+        // (first half: even rows + odd rows) + (second half: even + odd), a half being the WR of the training kernel --
+        // 8 rows up to 2 ranks, 16 up to 4, 32 up to 8; otherwise (all even rows) + (all odd rows).
+        constexpr bool kSegmented = res_blocks(L::kSegK) <= 2;
+        if constexpr (WR == 32 && (kWideRow || res_seq_halves(KT) || kSegmented)) {
           // up to 64 rows: polled in two halves one after the other -- 16 row pairs in flight per lane instead of 32, which
-          // these instantiations have no registers for (scratch otherwise) -- and added in the same order as in one go
+          // these instantiations have no registers for (scratch otherwise)
           const uint32_t rows_all = p.xchg_world * (uint32_t)kResGroups;
           unsigned va[16];
           alive = res_sweep<16, __HIP_MEMORY_SCOPE_SYSTEM>(L::rank_sums(p.xchg, region, tag & 1u, 0), GR, 32u * cb, tag, nvalid, min(rows_all, 32u), va,
                                                            &xb->abort_word, p.host_error, code, ticks, lane) && alive;
-          double acc = res_rows_add<16>(va, 0.0);
-          if (rows_all > 32u) {  // (uniform: 5 ... 8 ranks)
+          if (rows_all > 32u) {  // (uniform: 5 ... 8 ranks; the training kernels' halves are rows [0, 32) and [32, 64))
             unsigned vb[16];
             alive = res_sweep<16, __HIP_MEMORY_SCOPE_SYSTEM>(L::rank_sums(p.xchg, region, tag & 1u, 32u), GR, 32u * cb, tag, nvalid, rows_all - 32u, vb,
                                                              &xb->abort_word, p.host_error, code, ticks, lane) && alive;
-            acc = res_rows_add<16>(vb, acc);
+            if constexpr (kSegmented) {
+              s = res_segment<0, 16>(va) + res_segment<0, 16>(vb);
+            } else {
+              const double acc = res_rows_add<16>(vb, res_rows_add<16>(va, 0.0));
+              s = pair_add<32>(acc, acc);
+            }
+          } else if (kSegmented && p.xchg_world > 2u) {  // 3 or 4 ranks: halves of 16 rows
+            s = res_segment<0, 8>(va) + res_segment<8, 16>(va);
+          } else if (kSegmented) {                       // (2 ranks run the WR = 8 instantiation; kept for completeness: halves of 8 rows)
+            s = res_segment<0, 4>(va) + res_segment<4, 8>(va);
+          } else {
+            s = res_segment<0, 16>(va);
           }
-          s = pair_add<32>(acc, acc);
         } else {
         unsigned v2[WR];
         alive = res_sweep<WR, __HIP_MEMORY_SCOPE_SYSTEM>(L::rank_sums(p.xchg, region, tag & 1u, 0), GR, 32u * cb, tag, nvalid,
                                                          p.xchg_world * (uint32_t)kResGroups, v2, &xb->abort_word, p.host_error, code, ticks, lane) && alive;
-        s = res_sum<WR>(v2, lane);
+        if constexpr (kSegmented && (WR == 8 || WR == 16)) {
+          // (the launchers pick WR = 8 up to 2 ranks and -- ts_hybhol -- 16 up to 4: the training kernels' halves are WR rows each)
+          s = res_segment<0, WR / 2>(v2) + res_segment<WR / 2, WR>(v2);
+        } else {
+          s = res_sum<WR>(v2, lane);
+        }
         }
         // three levels (TSAMD_SCHEDULE_GATHER=leaders): only the eight leaders of a rank poll the world x 8 rows; each hands
         // the total -- the same bits on every leader of every rank -- to the members of its group through its local row

@@ -150,4 +150,24 @@ def test_hybrid_block_that_cannot_be_resident_is_replayed(ts, monkeypatch):
         its = [orc.snp_update(int(x)) for x in TRAIN] + [orc.snp_update(int(x), 1) for x in vlocs]
         assert eng.total_passes() == sum(its)
         assert_state_close(eng, orc, 1e-9, "replayed hybrid block")
+        # ... and with NO gamma step pending (advisor, round 5): above, a training update precedes the report, so the launch that
+        # fails at its entry is the one-entry ts_hybrid that applies the pending step, and the ts_hybhol launches queued behind it
+        # are merely aborted.  Here the previous call was a validation block: the first launch of the next block IS a ts_hybhol --
+        # its own entry failure, found in the journal by its launch offset, and its replay.
+        time.sleep(0.5)
+        eng.set_launch_mode(ts.LAUNCH_PER_SCHEDULE)
+        eng.run_schedule(vlocs[:7], 1)                  # batched again (ts_hybhol), undisturbed
+        eng.synchronize()
+        blocks = eng.holblock_info()["launches"]
+        assert blocks >= 1 and eng.recoveries() == 1
+        eng.debug_occupy(200, 400)
+        time.sleep(0.2)
+        eng.run_schedule(vlocs[::-1], 1)               # no step pending: every launch of this call is a ts_hybhol; the first gives up
+        eng.run_schedule(TRAIN2)
+        eng.synchronize()
+        assert eng.recoveries() == 2, eng.last_error()
+        assert eng.holblock_info()["launches"] > blocks   # (the failing launch WAS a block launch)
+        its += [orc.snp_update(int(x), 1) for x in vlocs[:7]] + [orc.snp_update(int(x), 1) for x in vlocs[::-1]] + [orc.snp_update(int(x)) for x in TRAIN2]
+        assert eng.total_passes() == sum(its)
+        assert_state_close(eng, orc, 1e-9, "replayed ts_hybhol launch")
     orc.close()
