@@ -38,6 +38,20 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (half the 157.3 TFLOP/s 
 SELFTEST_TOL = 1e-9    # exchange self-test: lambda / gamma vs the CPU oracle after 6 updates (rel)
 
 
+# One-GPU steady-state rates of the two BASELINE shapes that are sharded over a node (updates/s on ONE MI355X with everything resident,
+# 2 000-update launches: profiles/r06_other_configs.txt) and what sharding is expected to buy: strong scaling of this path is poor by
+# construction -- nine to ten DEPENDENT all-reduces per update, each a few microseconds of latency whatever the shard size.
+ONE_GPU_STEADY = {(1_000_000, 8): 13850.0, (1_000_000, 20): 3550.0}
+SCALING_NOTE = {
+    8: ("strong scaling (N fixed); ten dependent exchanges per update; predicted 1.2 / 1.3 / 1.4 x the one-GPU rate at 2 / 4 / 8 GPUs for K = 8 "
+        "(DESIGN.md section 5, predicted, never measured on a node): capacity, not speed, is what sharding buys this path"),
+    20: ("strong scaling (N fixed); ten dependent exchanges per update; K = 20 at N = 1M exceeds one GPU's register file (half its weights are "
+         "streamed there), so sharding also removes that stream: predicted 2.1 / 3.6 / 4.5 x the one-GPU rate at 2 / 4 / 8 GPUs "
+         "(DESIGN.md section 5, predicted, never measured on a node)"),
+    None: "strong scaling (N fixed); nine to ten dependent exchanges per update, each a few microseconds of latency whatever the shard size",
+}
+
+
 def resident_geometry(k):
     """(individuals per item, items per thread, items whose gamma stays in LDS) of the resident kernels --
     mirrors resident_vec / resident_items / sched_lds_items in csrc/tsamd_resident_kernels.h"""
@@ -285,7 +299,7 @@ def pmc_record_for(n, k, world, want, stale):
                 if then != now:
                     stale[0] = (f"profiles/pass_kernel_pmc.json was collected from other kernel sources (sha {then}, the tree "
                                 f"has {now}): its traffic / flops / latency figures are NOT used; re-profile "
-                                "(tools/r05/profile.sh) to refresh them")
+                                "(tools/r06/profile.sh) to refresh them")
                     return {}
                 return rec
     except Exception:  # noqa: BLE001
@@ -996,6 +1010,10 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_baseline": parity, "validation_block": validation,
             "legs": legs,
         }
+        if world > 1:
+            # what to read an N > 1 line against (stated BEFORE any node has run it: DESIGN.md section 5's predicted table)
+            out["predicted_1gpu_equiv"] = ONE_GPU_STEADY.get((n, k))
+            out["scaling_note"] = SCALING_NOTE.get(k, SCALING_NOTE[None])
         print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:

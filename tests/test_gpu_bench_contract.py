@@ -130,3 +130,5 @@ def test_bench_two_ranks_json_contract():
     vb = d["validation_block"]
     assert vb["locations"] == 10 and vb["heldout_per_location"] == 600 and 0 < vb["heldout_entries"] <= 6000 and vb["mean_loglik"] < 0
     assert sum(d["inner_passes_histogram"].values()) == 40
+    # round 6: an N > 1 line says what it is to be read against (no one-GPU rate is on record for this shape: null)
+    assert "predicted_1gpu_equiv" in d and d["predicted_1gpu_equiv"] is None and "dependent exchanges" in d["scaling_note"]
