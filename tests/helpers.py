@@ -64,3 +64,10 @@ def usable_cores():
         except (OSError, ValueError):
             pass
     return n
+
+
+def slow_params(values, fast):
+    """pytest parametrize values: those not in `fast` carry the `slow` marker (tests/conftest.py skips them unless TS_RUN_SLOW=1)"""
+    import pytest
+
+    return [v if v in fast else pytest.param(v, marks=pytest.mark.slow) for v in values]

@@ -100,14 +100,42 @@ def test_geometry_query_at_other_sizes(ts):
 
 
 def test_random_geometries_slice(ts):
-    """8 fixed-seed cases of the randomised stress (tests/stress_cases.py; 40 until round 5 -- the suite's time budget; the
-    tool runs hundreds: tools/stress_parity.py)"""
+    """8 fixed-seed cases of the randomised stress (tests/stress_cases.py) -- 40 with TS_RUN_SLOW=1, as until round 5 (the suite's
+    time budget); the tool runs hundreds: tools/stress_parity.py"""
+    import os
+
     from stress_cases import run_case
 
     rng = np.random.default_rng(20240)
     bad = []
-    for c in range(8):
+    for c in range(40 if os.environ.get("TS_RUN_SLOW", "0") not in ("", "0") else 8):
         ok, desc = run_case(ts, rng)
         if not ok:
             bad.append((c, desc))
     assert not bad, bad
+
+
+def test_workgroup_cap_knob_changes_the_geometry_not_the_results(ts, monkeypatch):
+    """TSAMD_SCHED_WORKGROUPS (round 6's tuning knob: fewer, fatter workgroups for the resident kernels -- the geometry sweep
+    of profiles/r06_experiments.md): the capped context runs more individuals per thread on fewer workgroups and reaches the
+    oracle's state all the same; the uncapped one is the default geometry."""
+    n, l, k = 60_000, 12, 8
+    eng, orc = pair(ts, n, l, k, 3300)
+    with eng:
+        base = eng.schedule_geometry()
+        eng.run_schedule(LOCS)
+        eng.synchronize()
+        its = [orc.snp_update(int(x)) for x in LOCS]
+        assert eng.total_passes() == sum(its)
+        assert_state_close(eng, orc, 1e-9, "default geometry")
+        lam0, gam0 = eng.get_lambda(), eng.get_gamma()
+    orc.close()
+    monkeypatch.setenv("TSAMD_SCHED_WORKGROUPS", "64")
+    eng, orc = pair(ts, n, l, k, 3300)
+    with eng:
+        geo = eng.schedule_geometry()
+        assert base["workgroups"] > 64 and geo["workgroups"] <= 64 and geo["indivs_per_thread"] > base["indivs_per_thread"], (base, geo)
+        eng.run_schedule(LOCS)
+        eng.synchronize()
+        assert rel_err(eng.get_lambda(), lam0) < 1e-10 and rel_err(eng.get_gamma(), gam0) < 1e-10   # (another order of the partial rows)
+    orc.close()

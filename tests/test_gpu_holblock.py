@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle_py as op
-from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, unpack_bed, usable_cores
+from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, slow_params, unpack_bed, usable_cores
 from test_gpu_parity import assert_state_close, ts  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -205,7 +205,7 @@ def test_block_that_cannot_be_resident_is_replayed(ts, monkeypatch):
     orc.close()
 
 
-@pytest.mark.parametrize("k", [1, 3] + list(range(2, 33, 2)) + [31])   # (the even K, 1, 3 and 31 here; the odd K in tests/test_gpu_hybrid.py)
+@pytest.mark.parametrize("k", slow_params(list(range(1, 33)), [1, 3] + list(range(2, 33, 2)) + [31]))   # (by default the even K, 1, 3 and 31 here and the odd K in tests/test_gpu_hybrid.py; TS_RUN_SLOW=1: every K in both)
 def test_every_instantiation_of_the_block(ts, k, monkeypatch):
     """ts_holblock<K> across K = 1 ... 32 (batches of 16 ... 4 locations, sub-batches of 4 / 2 / 1) on a shard of a few
     workgroups: bit for bit the entry-by-entry path, and the oracle at 1e-9"""

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle_py as op
-from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, usable_cores
+from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, slow_params, usable_cores
 from test_gpu_parity import assert_state_close, ts  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -108,7 +108,7 @@ def test_hybrid_block_equals_entry_by_entry_bitwise_and_the_oracle(ts, n, k, thr
     check(outs, orc, its, its_block, thresh)
 
 
-@pytest.mark.parametrize("k", [1, 4, 5, 8, 9, 12, 13, 14, 16, 17, 20, 21, 24, 27, 29, 32])
+@pytest.mark.parametrize("k", slow_params(list(range(1, 33)), [1, 4, 5, 8, 9, 12, 13, 14, 16, 17, 20, 21, 24, 27, 29, 32]))
 def test_instantiations_of_the_hybrid_block_on_a_small_device(ts, k, monkeypatch):
     """ts_hybhol<K> across K (every split: 4 / 2 / 1 locations per sweep, register / LDS / streamed items) on the launch
     geometry of a device with four compute units (TSAMD_TEST_MAX_WORKGROUPS, honoured with TSAMD_FLAG_TEST_HOOKS only), so that

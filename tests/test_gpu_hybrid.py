@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 import oracle_py as op
-from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, usable_cores
+from helpers import init_gamma, pack_bed, psd_genotypes, rel_err, slow_params, usable_cores
 from test_gpu_parity import assert_state_close, ts  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -148,7 +148,7 @@ def _on_chip_items(k):
     return reg, reg + min(16, (160 * 1024 - 1024 - 200 * k) // (k * 8 * 256))
 
 
-@pytest.mark.parametrize("k", [2] + list(range(1, 33, 2)) + [32])   # (the odd K, 2 and 32 here; the even K in tests/test_gpu_holblock.py: the suite's time budget)
+@pytest.mark.parametrize("k", slow_params(list(range(1, 33)), [2] + list(range(1, 33, 2)) + [32]))   # (by default the odd K, 2 and 32 here and the even K in tests/test_gpu_holblock.py: the suite's time budget; TS_RUN_SLOW=1: every K in both)
 def test_every_instantiation_on_a_small_device(ts, k, monkeypatch):
     """ts_hybrid<K> across K = 1 ... 32 -- with and without streamed items -- on four workgroups (TSAMD_TEST_MAX_WORKGROUPS:
     the geometry of a device with four compute units), so that a few thousand individuals fill the register items, the LDS
