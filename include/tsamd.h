@@ -250,8 +250,9 @@ int tsamd_probe_stream(tsamd_ctx *ctx, uint32_t reps, double *read_us, double *r
  * pass; 2 when all plain passes of a SNP run as one resident launch; 0 when a whole schedule runs as ONE launch with
  * the weights kept in registers), workgroups of the plain-pass and first-pass kernels.  The resident kernels need
  * k <= 32 and a shard that fits the register file of the GPU's compute units: 256 workgroups x
- *   k <= 8: 4096,  k = 9..16: 256 floor(128/k),  k = 17..24: 256 floor(112/k),  k = 25..32: 768   individuals
- * (1 048 576 per GPU at k <= 8, 524 288 at k = 16, 327 680 at k = 20); the whole-schedule kernel also nodekappa == 0.5.
+ *   k <= 8: 4096,  k = 9..16: 256 floor(128/k),  k = 17..24: 256 floor(112/k) (k = 22: 1024),  k = 25..32: 768   individuals
+ * (1 048 576 per GPU at k <= 8, 524 288 at k = 16, 327 680 at k = 20; per RANK of a sharded run one 256-thread round less at
+ * k = 14 and k = 16: 524 288 / 458 752); the whole-schedule kernel also nodekappa == 0.5.
  * A LARGER shard (k <= 32, nodekappa == 0.5, one GPU or up to 4 ranks connected peer to peer) still runs a whole schedule
  * as ONE launch (kernels_per_snp == 0): ts_hybrid keeps the weights of the first individuals of every thread in registers
  * and LDS and re-reads the others every pass (tsamd_schedule_geometry: on_chip_per_thread < indivs_per_thread); it has no

@@ -16,7 +16,8 @@ static_assert(TSAMD_K <= kResidentMaxK, "ts_holblock holds the shard's weights i
 // geometry as ts_schedule (its per-thread partial sums are the same sums)
 void TSAMD_CAT(launch_holblock_k, TSAMD_K)(uint32_t grid, uint32_t chunk, hipStream_t stream, const DevParams &p, uint32_t par,
                                            const uint32_t *sched, uint32_t n, uint32_t serial) {
-  // (a sharded context: the instantiation whose level 2 spans up to 8 ranks' group leaders -- 32 row pairs per lane)
+  // (a sharded context: the instantiation whose level 2 spans the ranks' group leaders -- WR = 8 up to 2 ranks; 32 above: up to 64
+  // rows, polled 16 row pairs at a time)
   if (p.xchg_world == 0u)
     hipLaunchKernelGGL((ts_holblock<TSAMD_K, 0>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.w, p.npad, chunk, par, sched, n, p.res, serial, p);
   else if (p.xchg_world <= 2u)

@@ -7,7 +7,7 @@
 // file.  Per K a thread holds resident_items(K) items of one individual each:
 //   K <= 8      16 items                                         -> 1 048 576 individuals per GPU
 //   K = 9..16   floor(128 / K) items (14 at K = 9 ... 8 at K = 16)  -> 917 504 ... 524 288
-//   K = 17..24  floor(112 / K) items (6 at K = 17 ... 4 at K = 24)  -> 393 216 ... 262 144
+//   K = 17..24  floor(112 / K) items (6 at K = 17 ... 4 at K = 24; K = 22: 4)  -> 393 216 ... 262 144
 //   K = 25..32  3 items                                           -> 196 608
 // i.e. at most 128 doubles = 256 registers of weights per thread (the AGPR half of the file) next to the gamma
 // step's K-sized temporaries (which is why the budget shrinks as K grows).  Between passes the workgroups all-reduce their partial rows INSIDE the launch
@@ -56,7 +56,7 @@ constexpr int sched_items(int k, int wr) { return wr > 0 ? sharded_items(k) : re
 //   level 1: the workgroups of group g = blockIdx % 8 (= the XCD) publish rows(g, blockIdx / 8); the group's leader
 //            (blockIdx < 8) re-reads them until every tag matches, adds them in member order, publishes sums(g);
 //   level 2: every workgroup re-reads the 8 group rows and adds them in group order (sharded: world x 8 rows in its
-//            own rank's Xchg::res_sums, written by the leaders of all ranks over xGMI).
+//            own rank's Xchg::res_sums, written by the leaders of all ranks over xGMI -- polled in two halves, res_split).
 // A single workgroup exchanges nothing.  Up to kResOneLevelGrid = 32 workgroups on one GPU (shards up to 8 192 individuals:
 // the sizes of real cohorts; K <= 8 only in ts_resident) there is only ONE level: every workgroup sweeps every row.  The layouts of the two forms overlap, which
 // is harmless: an exchange is self-contained (tags never repeat).

@@ -24,7 +24,9 @@ static_assert(sizeof(((Xchg *)nullptr)->res_sums) / sizeof(unsigned long long) >
 // n entries at `sched` (pinned host or device memory), starting from and leaving the State of parity par.
 // A chunk that fills all items of its threads runs the kernel without the skip-unused-items branches; a sharded
 // context (p.xchg_world ranks connected peer to peer) runs the instantiation whose level 2 spans the ranks' group
-// leaders (8 row pairs per lane for up to 2 ranks, 16 for up to 4, 32 for up to 8).
+// leaders: WR = 8 rows per half for up to 2 ranks, 16 for up to 4, 32 for up to 8 -- up to K = 16 the two halves of the
+// world x 8 rows are polled by two waves side by side (WR / 2 row pairs per lane), above by one wave per column block
+// (res_exchange, tsamd_resident_kernels.h).
 #define TSAMD_SCHED_LAUNCH(PARTIAL, WR)                                                                                               \
   hipLaunchKernelGGL((ts_schedule<TSAMD_K, (PARTIAL) || kAlwaysPartial, WR>), dim3(grid), dim3(kResidentBlock), 0, stream, p.ctl, p.w, p.npad, \
                      chunk, par, sched, n, p.res, serial, p)
