@@ -24,8 +24,10 @@ def test_no_whole_launch_kernel_the_launchers_can_select_uses_scratch(rows):
     (csrc/tsamd_sched.hip, tsamd_hol.hip, tsamd_hyb.hip, tsamd_hhol.hip): K = 1 ... 32, every PARTIAL / WR / STREAM form"""
     fams = ("ts_schedule<", "ts_holblock<", "ts_hybrid<", "ts_hybhol<")
     sel = [r for r in rows if r["name"].startswith(fams)]
-    assert len(sel) == (8 * 8 + 24 * 4) + 32 * 3 + 32 * 6 + sum(1 for r in sel if r["name"].startswith("ts_hybhol<")), len(sel)
-    assert sum(1 for r in sel if r["name"].startswith("ts_hybhol<")) >= 32 * 3
+    count = {f: sum(1 for r in sel if r["name"].startswith(f)) for f in fams}
+    # ts_schedule: K <= 8 with and without the skip branches x WR in {0, 8, 16, 32}, above only with them; ts_holblock: WR in {0, 8, 32};
+    # ts_hybrid: WR in {0, 8, 16} x with / without streamed items; ts_hybhol: WR in {0, 8, 16}
+    assert count == {"ts_schedule<": 8 * 8 + 24 * 4, "ts_holblock<": 32 * 3, "ts_hybrid<": 32 * 6, "ts_hybhol<": 32 * 3}, count
     bad = [(r["name"], r["private_segment_fixed_size"]) for r in sel if r["private_segment_fixed_size"] != 0]
     assert not bad, f"whole-launch kernels with scratch: {bad}"
     for r in sel:  # one wave per SIMD: the whole 512-entry file, nothing beyond it
