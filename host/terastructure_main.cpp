@@ -835,15 +835,19 @@ void load_gamma(Run &r) {
   }
   set_gamma_all(r, g);
   FILE *f = fopen(r.file_str("/gammasave.txt").c_str(), "w");
-  if (f) {
+  if (f) {  // (id, label, K x "%.8f\t", argmax: src/snpsamplinge.cc:846-860 -- the values through fmt_fixed8, the bytes of "%.8f")
+    std::vector<char> line(k * (tsfmt::kMaxLen + 1) + 1);
     for (size_t i = 0; i < n; ++i) {
       fprintf(f, "%zu\t%s\t", i, (i < r.labels.size() && !r.labels[i].empty()) ? r.labels[i].c_str() : "unknown");
       double mx = .0;
       size_t mk = 0;
+      char *p = line.data();
       for (size_t j = 0; j < k; ++j) {
-        fprintf(f, "%.8f\t", g[i * k + j]);
+        p = tsfmt::fmt_fixed8(p, g[i * k + j]);
+        *p++ = '\t';
         if (g[i * k + j] > mx) mx = g[i * k + j], mk = j;
       }
+      fwrite(line.data(), 1, (size_t)(p - line.data()), f);
       fprintf(f, "%zu\n", mk);
     }
     fclose(f);

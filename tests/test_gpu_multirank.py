@@ -163,6 +163,8 @@ def test_sharded_schedule_kernel_matches_oracle(tmp_path, world, n, k, thresh, m
     with a pass cap of 3.  The same shards with one launch per pass (TS_LAUNCH_MODE=0) must agree to rounding."""
     l, seed, nsnp = 24, 77, 40
     env, over = {"TS_EXPECT_KPS": "0"}, {}
+    if world == 8:
+        nsnp = 24   # (eight processes time-slicing one GPU's queues run a few updates per second: the suite's time budget)
     if n > 1_000_000:
         if _n_devices() >= world:
             pytest.skip("the full-size K <= 8 instantiation needs the ranks to share one device (16 individuals per thread)")
@@ -262,6 +264,8 @@ def test_sharded_validation_block_is_batched_and_matches(tmp_path, world, n, k, 
     (wide rows exchanged across the ranks through Xchg::res_wide).  Against the oracle, and bit for bit against the same run
     with TSAMD_HOLBLOCK=0 (entry by entry inside ts_schedule)."""
     l, seed, nsnp, nhol = 24, 81, 20, 21
+    if world == 8:
+        nsnp, nhol = 12, 18   # (see test_sharded_schedule_kernel_matches_oracle: a few updates per second with 8 ranks on one GPU)
     env, over = {"TS_EXPECT_KPS": "0", "TS_HOL_LOCS": str(nhol), "TS_EXPECT_HOLBLOCKS": "1"}, {}
     if thresh is not None:
         env["TS_CONV_THRESH"] = str(thresh)
