@@ -126,9 +126,11 @@ template <int KT, int WR>
 __device__ __forceinline__ double res_total(const double *s_tot, uint32_t i) {
   if constexpr (res_split<KT, WR>()) return s_tot[i] + s_tot[4u * (uint32_t)KT + i]; else return s_tot[i];
 }
-// rows of three or four column blocks (K >= 17) on 5 ... 8 ranks: every wave already polls a block of its own, 32 row pairs per
-// lane in one go -- except where that instantiation would spill to scratch (profiles/r06_kernel_resources.txt): two halves,
-// one after the other (one more memory round trip per exchange)
+// 5 ... 8 ranks (WR = 32), the K whose instantiation would otherwise still spill to scratch (profiles/r06_kernel_resources.txt):
+//   K = 18 (rows of three column blocks: every wave polls a block of its own, 32 row pairs per lane in one go at the other K >= 17)
+//          polls its 32 pairs as 16 + 16, one after the other;
+//   K = 16 (split as above: 16 pairs per lane and wave) polls them as 8 + 8
+// -- one more memory round trip per exchange, added in the same order as in one go.
 constexpr bool res_seq_halves(int k) { return k == 18 || k == 16; }
 // doubles of s_tot a kernel with narrow rows of 2 KT values provides
 template <int KT, int WR>
@@ -136,7 +138,8 @@ constexpr int res_tot_doubles() { return (res_split<KT, WR>() ? 8 : 4) * KT; }
 
 // the same row / sum / flat positions for rows of 2 KX values in ResXchg::wide (one region)
 // KS: the K of the context (rows of 2 KS values in its training kernels): a sharded exchange adds the ranks' rows in the order
-// those kernels do (res_segmented below), so that a batched validation block equals the entry-by-entry path bit for bit
+// those kernels do (kSegmented / res_segment in res_exchange), so that a batched validation block equals the entry-by-entry path
+// bit for bit
 template <int KX, int KS = KX>
 struct WideLay {
   static constexpr int kSegK = KS;
