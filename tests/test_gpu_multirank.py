@@ -48,7 +48,7 @@ def _run_ranks(tmp_path, mode, world, n, l, k, seed, nsnp, extra_env=None, ok_co
     outs = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=180)
+            out, _ = p.communicate(timeout=110)   # (the slowest case takes 28 s; a rendezvous that never completes must not cost the suite 3 minutes)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
