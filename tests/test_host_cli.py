@@ -5,6 +5,7 @@ import itertools
 import os
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -307,3 +308,36 @@ def test_individual_major_bed_equals_snp_major(host_bin, tmp_path):
     keys = ("missing snps", "0s snps", "1s snps", "2s snps", "total validation snps")
     pick = lambda txt: [ln for ln in txt.splitlines() if ln.startswith(keys)]  # noqa: E731
     assert pick(a["param.txt"]) == pick(b["param.txt"])
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_at_scale(host_bin, tmp_path):
+    """The drop-in binary at a BASELINE number of individuals (5 s; the full-size runs are profiles/r06_cli_end_to_end.txt): N = 100 000 individuals (config 3's), L = 20 000, K = 8 -- a synthetic PSD .bed generated on
+    the GPU (tools/make_synth_bed.py), two report periods.  Checks what the reference's files promise -- theta rows sum to 1,
+    gamma.txt / theta.txt have N rows of K "%.8f" values with a trailing tab, the held-out log-likelihood improves from its initial
+    value -- and what round 6 added: save_model is off the critical path (timing.txt) and every file is complete when the process ends."""
+    n, l, k = 100_000, 20_000, 8
+    free = shutil.disk_usage(tmp_path).free
+    if free < 2 * (1 << 30):
+        pytest.skip(f"needs 2 GB of scratch space, {free >> 30} GB free")
+    prefix = str(tmp_path / "e2e")
+    g = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_bed.py"), prefix, str(n), str(l), str(k)],
+                       capture_output=True, text=True, timeout=600)
+    assert g.returncode == 0, g.stderr[-2000:]
+    cmd = [host_bin, "-file", "e2e.bed", "-n", str(n), "-l", str(l), "-k", str(k), "-stochastic", "-nthreads", "1", "-label", "e2e",
+           "-rfreq", "5000", "-max-iter", "10200"]
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2000:])
+    run = tmp_path / f"n{n}-k{k}-l{l}-e2e"
+    for name in ("gamma.txt", "theta.txt"):
+        rows = open(run / name).read().split("\n")
+        assert rows[-1] == "" and len(rows) == n + 1                       # complete: N lines, the last one terminated
+        assert all(ln.endswith("\t") and ln.count("\t") == k for ln in rows[:-1:997])
+    theta = _read_matrix(run / "theta.txt")
+    assert theta.shape == (n, k) and np.max(np.abs(theta.sum(axis=1) - 1.0)) < 1e-6
+    val = [ln.split("\t") for ln in open(run / "validation.txt").read().splitlines()]
+    assert len(val) == 3 and float(val[-1][2]) > float(val[0][2])            # initial + two reports; the fit improves
+    tm = dict(ln.split(": ", 1) for ln in open(run / "timing.txt").read().splitlines() if ": " in ln and not ln.startswith("#"))
+    training = float(tm["training"])
+    blocked = float(tm["save_model, main thread blocked"].split(" ")[0])
+    assert training > 0 and blocked < 0.5 * training, tm                     # (the writer thread does the formatting)
