@@ -155,7 +155,13 @@ def test_p2p_small_pass_caps(tmp_path, world, max_inner):
                                                         # and the full-size instantiation <8, false, 32>: 16 individuals per thread on each rank's
                                                         # share of the device (config 4's N on 8 ranks)
                                                         (4, 120_000, 8, None, None), (8, 200_000, 8, None, None), (8, 200_000, 6, 20.0, None),
-                                                        (8, 1_040_000, 8, None, None)])
+                                                        (8, 1_040_000, 8, None, None),
+                                                        # the 8-rank polls that take their row pairs in two goes (res_seq_halves): K = 16 (two waves per
+                                                        # block, 8 + 8 pairs), K = 18 (one wave per block, 16 + 16), and K = 14 (8 items per thread when
+                                                        # sharded) -- slow: TS_RUN_SLOW=1
+                                                        pytest.param(8, 100_000, 16, None, None, marks=pytest.mark.slow),
+                                                        pytest.param(8, 100_000, 18, None, None, marks=pytest.mark.slow),
+                                                        pytest.param(8, 100_000, 14, None, None, marks=pytest.mark.slow)])
 def test_sharded_schedule_kernel_matches_oracle(tmp_path, world, n, k, thresh, max_inner):
     """Shards of at least 8 workgroups, K <= 32: every rank runs the whole schedule as ONE launch (ts_schedule) whose
     in-launch exchange spans the ranks -- group sums stored into every rank's buffer, each rank polls its own copy.
@@ -258,7 +264,9 @@ def test_sharded_hybrid_kernel_matches_oracle(tmp_path, world, n, k, thresh):
 @pytest.mark.parametrize("world,n,k,thresh", [(2, 40_000, 8, None), (4, 90_000, 16, None), (3, 50_000, 5, 6.0),
                                               # round 6: ts_holblock<8, 32> / <20, 32> on 8 ranks (configs 4 and 5; the wide rows' level 2
                                               # polled in two halves of 32 rows)
-                                              (8, 200_000, 8, None), (8, 125_000, 20, 8.0)])
+                                              (8, 200_000, 8, None), (8, 125_000, 20, 8.0),
+                                                        pytest.param(8, 100_000, 16, None, marks=pytest.mark.slow),    # halves of 32 rows, K <= 16: segmented order
+                                                        pytest.param(5, 100_000, 12, None, marks=pytest.mark.slow)])   # 5 ranks: 40 rows, the second half partly filled
 def test_sharded_validation_block_is_batched_and_matches(tmp_path, world, n, k, thresh):
     """A validation-mode schedule on a sharded context that runs ts_schedule: every rank runs it as ts_holblock<K, WR> launches
     (wide rows exchanged across the ranks through Xchg::res_wide).  Against the oracle, and bit for bit against the same run
