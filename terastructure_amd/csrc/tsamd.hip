@@ -539,7 +539,13 @@ void choose_sharded_schedule(tsamd_ctx *c) {
     return;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, c->dev) != hipSuccess || prop.multiProcessorCount <= 0) return;
-  uint32_t cap = std::min<uint32_t>((uint32_t)(kResGroups * kResMembers), (uint32_t)prop.multiProcessorCount / c->device_share);
+  // (ranks sharing a device: the dispatcher deals a launch's workgroups round robin over the 8 XCDs, every rank's launch starting at the
+  // same one, so a rank may take floor(compute units per XCD / ranks) per XCD -- 3 ranks: 80 workgroups each, not 256 / 3 = 85, which put 33
+  // workgroups on five XCDs of 32 compute units and lost the launch to the co-residency check: every 3-rank ts_hybrid test of round 5 in fact ran
+  // its replay.  One rank per device: all compute units.)
+  const uint32_t per_xcd = (uint32_t)prop.multiProcessorCount / (uint32_t)kResGroups;
+  uint32_t cap = std::min<uint32_t>((uint32_t)(kResGroups * kResMembers),
+                                    c->device_share > 1u ? (uint32_t)kResGroups * (per_xcd / c->device_share) : (uint32_t)prop.multiProcessorCount);
   if (env_u32("TSAMD_SCHED_WORKGROUPS", 0) >= (uint32_t)kResGroups) cap = std::min<uint32_t>(cap, env_u32("TSAMD_SCHED_WORKGROUPS", 0));  // (tuning knob, see tsamd_create)
   if (cap < (uint32_t)kResGroups) return;
   uint32_t my_grid = 0, my_chunk = 0;

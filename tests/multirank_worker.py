@@ -99,14 +99,15 @@ def main():
         eng.synchronize()
         info = eng.holblock_info()
         want = int(os.environ.get("TS_EXPECT_HOLBLOCKS", "-1"))
-        assert want < 0 or info["launches"] == want, info
+        assert want < 0 or info["launches"] == want, (info, eng.recoveries(), eng.last_error(), eng.launch_info())
     if os.environ.get("TS_EXPECT_RECOVERIES"):
         assert eng.recoveries() == int(os.environ["TS_EXPECT_RECOVERIES"]), f"recoveries: {eng.recoveries()} ({eng.last_error()})"
-        assert eng.launch_info()["kernels_per_snp"] == eng.cfg.max_inner
+        if int(os.environ["TS_EXPECT_RECOVERIES"]) > 0:
+            assert eng.launch_info()["kernels_per_snp"] == eng.cfg.max_inner
     full = tdist.gather_rows(eng.get_gamma(), n, d, ts.shard_range)
     cnt = tdist.gather_rows(eng.get_counts().astype(np.float64)[:, None], n, d, ts.shard_range)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), lam=eng.get_lambda(), gamma=full, cnt=cnt, its=np.array(its),
-             passes=eng.total_passes(), kps=kps)
+             passes=eng.total_passes(), kps=kps, recoveries=eng.recoveries())
     d.barrier()
     eng.close()
     d.barrier()
