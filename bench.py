@@ -986,6 +986,10 @@ def main():
     m = measure_legs(args, ts, eng, dist, rank, world, local_rank, n, l, k, sc, locs, cores, oracle_ok, gamma_init)
     roofline, cpu, parity, validation, legs = m["roofline"], m["cpu_baseline"], m["parity"], m["validation_block"], m["legs"]
 
+    try:
+        recoveries = int(eng.recoveries())
+    except Exception:  # noqa: BLE001
+        recoveries = None
     if rank == 0:
         alg_update = (mean_passes + 4) * 8.0 * n * k + (mean_passes + 1) * n / 4.0 + 8.0 * n
         out = {
@@ -1009,6 +1013,9 @@ def main():
                                "device is at its steady clocks when the timed region starts (--ramp-seconds 0 disables)")},
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_baseline": parity, "validation_block": validation,
             "legs": legs,
+            # resident launches of rank 0's context that found compute units taken and were replayed one launch per pass (0 on a GPU
+            # of one's own: a non-zero count means `value` was not measured on the kernel `roofline.kernel` names)
+            "recoveries": recoveries,
         }
         if world > 1:
             # what to read an N > 1 line against (stated BEFORE any node has run it: DESIGN.md section 5's predicted table)

@@ -68,6 +68,7 @@ def test_bench_json_contract():
     assert 0 < vb["heldout_entries"] <= 5 * 300 and vb["mean_loglik"] < 0
     assert all(v == "ok" for v in d["legs"].values()), d["legs"]              # every secondary leg ran (each in its own try)
     assert {"roofline_timed_kernel", "roofline_other_launch_modes", "cpu_baseline", "parity_vs_cpu_baseline", "validation_block"} <= set(d["legs"])
+    assert d["recoveries"] == 0                                               # (the timed kernel is the one the line names: nothing was replayed)
 
 
 def test_bench_short_run_matches_long_run():
@@ -132,3 +133,4 @@ def test_bench_two_ranks_json_contract():
     assert sum(d["inner_passes_histogram"].values()) == 40
     # round 6: an N > 1 line says what it is to be read against (no one-GPU rate is on record for this shape: null)
     assert "predicted_1gpu_equiv" in d and d["predicted_1gpu_equiv"] is None and "dependent exchanges" in d["scaling_note"]
+    assert d["recoveries"] == 0                                    # (no launch of the timed context was replayed)
